@@ -1,0 +1,268 @@
+"""Generate golden fixtures by importing the REAL reference (build container only).
+
+    python tests/golden/make_golden.py            # writes tests/golden/*.npz
+
+/root/reference does not exist on the GPU box, so this script is never run by
+tests; it only documents (and reproduces) how the committed vectors were made.
+Nothing from the reference is copied: the outputs are data — seeded inputs,
+the state-dict the reference's own constructors produced, and the tensors its
+own forward/backward returned.
+"""
+import os
+import sys
+import shutil
+import tempfile
+import types
+
+import numpy as np
+
+np.bool8 = np.bool_            # reference uses the numpy<2 alias (dataset.py:188, BaseModel.py:278)
+import torch
+
+REF = "/root/reference/src"
+OUT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REF)
+
+from models.modules import encoder as R_enc                # noqa: E402
+from models.modules import attention as R_att              # noqa: E402
+from models.TwoTower import TwoTowerModel                  # noqa: E402
+from utils import util as R_util                           # noqa: E402
+
+sys.path.insert(0, OUT)
+from seeded import seeded_state                            # noqa: E402
+
+torch.set_num_threads(4)
+
+
+def make_plm_dir(root, vocab, dim, heads):
+    """random-init BERT-shaped directory (the reference loads word embeddings
+    from AutoModel.from_pretrained(manager.plm_dir), encoder.py:29,119)."""
+    from transformers import BertConfig, BertModel
+    cfg = BertConfig(vocab_size=vocab, hidden_size=dim, num_hidden_layers=1,
+                     num_attention_heads=heads, intermediate_size=2 * dim,
+                     max_position_embeddings=64)
+    d = os.path.join(root, f"plm_{vocab}_{dim}")
+    if not os.path.exists(d):
+        torch.manual_seed(1234)
+        BertModel(cfg).save_pretrained(d)
+    return d
+
+
+def fake_manager(plm_dir, E, D, H, L, T, K):
+    return types.SimpleNamespace(
+        plm_dim=E, plm_dir=plm_dir, hidden_dim=D, head_num=H, his_size=L,
+        sequence_length=T, device="cpu", rank=0, world_size=1, negative_num=K,
+        verbose=None, enable_fields=["title"], dropout_p=0.1)
+
+
+def synth_news_table(g, Nn, T, V):
+    """MIND-like token table: row 0 all PAD; others [CLS] w… [SEP] PAD…
+    (dataset.py:68-103).  A few rows are left empty (no title)."""
+    ids = torch.zeros(Nn, T, dtype=torch.int64)
+    msk = torch.zeros(Nn, T, dtype=torch.int64)
+    for i in range(1, Nn):
+        if i % 11 == 7:
+            continue                                        # news without a title
+        n = int(torch.randint(3, T + 1, (1,), generator=g))
+        ids[i, :n] = torch.randint(min(200, V // 2), V, (n,), generator=g)
+        ids[i, 0] = 101 % V
+        ids[i, n - 1] = 102 % V
+        msk[i, :n] = 1
+    return ids, msk
+
+
+def synth_batch(g, B, C, L, Nn, ids, msk):
+    cdd_idx = torch.randint(1, Nn, (B, C), generator=g)
+    cdd_idx[0, -1] = 0                                      # zero-padded negative (util.py:72-76)
+    his_idx = torch.zeros(B, L, dtype=torch.int64)
+    his_mask = torch.zeros(B, L, dtype=torch.int64)
+    for b in range(B):
+        n = int(torch.randint(0, L + 1, (1,), generator=g)) if b else 0   # row 0: empty history
+        his_idx[b, :n] = torch.randint(1, Nn, (n,), generator=g)
+        if n == 0:
+            his_mask[b, 0] = 1                              # dataset.py:140-141
+        else:
+            his_mask[b, :n] = 1
+    return dict(cdd_idx=cdd_idx, his_idx=his_idx, his_mask=his_mask,
+                cdd_token_id=ids[cdd_idx], cdd_attn_mask=msk[cdd_idx],
+                his_token_id=ids[his_idx], his_attn_mask=msk[his_idx],
+                label=torch.zeros(B, dtype=torch.int64))
+
+
+NEWS = {"cnn": R_enc.CnnNewsEncoder, "tfm": R_enc.TfmNewsEncoder}
+USER = {"rnn": R_enc.RnnUserEncoder, "sum": R_enc.SumUserEncoder, "avg": R_enc.AvgUserEncoder,
+        "attn": R_enc.AttnUserEncoder, "tfm": R_enc.TfmUserEncoder}
+
+
+def dump_pair(tmp, tag, ne, ue, V, E, D, H, T, L, K, B, Nn, seed, big=False):
+    plm = make_plm_dir(tmp, V, E, max(1, H if E % H == 0 else 1))
+    mgr = fake_manager(plm, E, D, H, L, T, K)
+    torch.manual_seed(seed)
+    model = TwoTowerModel(mgr, NEWS[ne](mgr), USER[ue](mgr))
+    # make every parameter non-trivial (biases / LayerNorm default to 0 / 1)
+    g = torch.Generator().manual_seed(seed + 1)
+    with torch.no_grad():
+        if big:
+            # weights regenerated from a seed by the tests (tests/golden/seeded.py)
+            names = [(n, p.shape) for n, p in model.named_parameters()]
+            st = seeded_state(names, seed)
+            for n, p in model.named_parameters():
+                p.copy_(st[n])
+        else:
+            for n, p in model.named_parameters():
+                if n.endswith("bias"):
+                    p.copy_(0.1 * torch.randn(p.shape, generator=g))
+                if "LayerNorm.weight" in n:
+                    p.copy_(1 + 0.1 * torch.randn(p.shape, generator=g))
+    model.eval()                                            # dropout off: RNG streams are not portable
+    ids, msk = synth_news_table(g, Nn, T, V)
+    x = synth_batch(g, B, K + 1, L, Nn, ids, msk)
+
+    out = {}
+    tok, cdd = model._encode_news(x)
+    _, his = model._encode_news(x, cdd=False)
+    user = model._encode_user(x)
+    logits = model._compute_logits(cdd, user)
+    loss = model(x)
+    model.zero_grad()
+    loss.backward()
+    out.update(cdd_news=cdd, his_news=his, user=user, logits=logits, loss=loss)
+    if tok.numel() < 200000:
+        out["cdd_token_emb"] = tok
+    with torch.no_grad():
+        # cached evaluation: reference builds the table on rank 0 in batches (BaseModel.py:227-234)
+        cache = torch.cat([model.newsEncoder(ids[s:s + 7], msk[s:s + 7])[1] for s in range(0, Nn, 7)], 0)
+        model.news_embeddings = cache
+        out["news_cache"] = cache
+        out["infer_logits"] = model.infer(x)
+
+    blob = {}
+    for k, v in x.items():
+        blob["in." + k] = v.numpy()
+    blob["in.news_token_ids"] = ids.numpy()
+    blob["in.news_attn_masks"] = msk.numpy()
+    if big:
+        blob["w_names"] = np.asarray([n for n, _ in model.named_parameters()])
+        blob["w_shapes"] = np.asarray([";".join(map(str, p.shape)) for _, p in model.named_parameters()])
+        blob["w_abs_sum"] = np.asarray([p.detach().double().abs().sum().item() for _, p in model.named_parameters()])
+        blob["w_seed"] = np.asarray(seed)
+    else:
+        for k, v in model.state_dict().items():
+            blob["w." + k] = v.detach().numpy()
+    for k, v in out.items():
+        blob["out." + k] = v.detach().numpy()
+    for n, p in model.named_parameters():
+        gr = p.grad.detach()
+        if big:
+            # large tensors: a strided sample + an abs-sum checksum
+            flat = gr.reshape(-1)
+            step = max(1, flat.numel() // 4096)
+            blob["g_step." + n] = np.asarray(step)
+            blob["g." + n] = flat[::step].numpy()
+            blob["g_abs_sum." + n] = np.asarray(gr.double().abs().sum().item())
+        else:
+            blob["g." + n] = gr.numpy()
+    blob["meta"] = np.asarray([V, E, D, H, T, L, K, B, Nn], dtype=np.int64)
+    path = os.path.join(OUT, f"{tag}.npz")
+    np.savez_compressed(path, **blob)
+    print(f"{tag}: loss={loss.item():.6f}  {os.path.getsize(path) / 1024:.1f} KiB")
+
+
+def dump_primitives():
+    """attention.py functions on adversarial masks (fully masked rows with
+    DIFFERENT tokens: the 2^-7 quantisation trap)."""
+    g = torch.Generator().manual_seed(7)
+    D, S, N, H = 24, 9, 6, 4
+    q = torch.randn(1, D, generator=g)
+    key = torch.randn(N, S, D, generator=g) * 3
+    val = torch.randn(N, S, D, generator=g)
+    mask = (torch.rand(N, S, generator=g) > 0.4).long()
+    mask[0] = 0                                             # fully masked
+    mask[1] = 1
+    out, prob = R_att.scaled_dp_attention(q, key, val, attn_mask=mask.unsqueeze(-2), return_prob=True)
+    out_nomask = R_att.scaled_dp_attention(q, key, val)
+    torch.manual_seed(11)
+    layer = R_att.TFMLayer(D, H, 0.1).eval()
+    with torch.no_grad():
+        for n, p in layer.named_parameters():
+            if n.endswith("bias"):
+                p.copy_(0.1 * torch.randn(p.shape, generator=g))
+    x = torch.randn(N, S, D, generator=g)
+    y = layer(x, attention_mask=mask)
+    blob = dict(q=q, key=key, val=val, mask=mask, out=out, prob=prob, out_nomask=out_nomask, x=x, y=y)
+    blob = {k: v.detach().numpy() for k, v in blob.items()}
+    for k, v in layer.state_dict().items():
+        blob["w." + k] = v.numpy()
+    blob["meta"] = np.asarray([D, S, N, H], dtype=np.int64)
+    np.savez_compressed(os.path.join(OUT, "primitives.npz"), **blob)
+    print("primitives ok")
+
+
+def dump_metrics():
+    """utils/util.py metric + packing functions on a fixed ragged result set
+    with exact ties, duplicated news inside an impression and padded rows."""
+    rng = np.random.RandomState(5)
+    n_impr, Ce = 37, 6
+    impr_indices, masks, labels, preds = [], [], [], []
+    for imp in range(n_impr):
+        n = rng.randint(2, 15)
+        lab = (rng.rand(n) < 0.3).astype(np.int64)
+        lab[rng.randint(n)] = 1
+        lab[(np.argmax(lab) + 1) % n] = 0
+        sc = rng.randn(n).astype(np.float32)
+        if imp % 5 == 0:
+            sc[rng.randint(n)] = sc[0]                      # exact tie
+        if imp % 7 == 0:
+            sc = np.round(sc, 1)                            # many ties
+        for s in range(0, n, Ce):                           # chunk rows like cache_behaviors (dataset.py:388-390)
+            m = min(Ce, n - s)
+            impr_indices.append(imp)
+            masks.append(np.arange(Ce) < m)
+            labels.append(np.concatenate([lab[s:s + m], -np.ones(Ce - m, dtype=np.int64)]))
+            preds.append(np.concatenate([sc[s:s + m], rng.randn(Ce - m).astype(np.float32)]))
+    masks = np.asarray(masks, dtype=np.bool_)
+    labels = np.asarray(labels, dtype=np.int32)
+    preds = np.asarray(preds, dtype=np.float32)
+    glabels, gpreds = R_util.pack_results(impr_indices, masks, labels, preds)
+    res = R_util.compute_metrics(glabels, gpreds, ["auc", "mean_mrr", "ndcg@5", "ndcg@10"])
+    per = np.asarray([[R_util.roc_auc_score(l, p), R_util.mrr_score(np.asarray(l), np.asarray(p)),
+                       R_util.ndcg_score(np.asarray(l), np.asarray(p), 5),
+                       R_util.ndcg_score(np.asarray(l), np.asarray(p), 10)] for l, p in zip(glabels, gpreds)])
+    shards = np.asarray([[ws, r, R_util.Sequential_Sampler(n, ws, r).start, R_util.Sequential_Sampler(n, ws, r).end, n]
+                         for n in (0, 1, 7, 10, 1001, 376471) for ws in (1, 2, 3, 8) for r in range(ws)], dtype=np.int64)
+    np.savez_compressed(
+        os.path.join(OUT, "metrics.npz"),
+        impr_indices=np.asarray(impr_indices), masks=masks, labels=labels, preds=preds,
+        group_sizes=np.asarray([len(l) for l in glabels]),
+        group_labels=np.concatenate([np.asarray(l) for l in glabels]),
+        group_preds=np.concatenate([np.asarray(p, dtype=np.float32) for p in gpreds]),
+        per_impression=per, shards=shards,
+        result=np.asarray([res["auc"], res["mean_mrr"], res["ndcg@5"], res["ndcg@10"]]))
+    print("metrics", res)
+
+
+def main():
+    tmp = tempfile.mkdtemp(prefix="golden_plm_")
+    try:
+        dump_primitives()
+        dump_metrics()
+        seed = 100
+        for ne in ("cnn", "tfm"):
+            for ue in ("rnn", "sum", "avg", "attn", "tfm"):
+                E = 24
+                D = 24 if ne == "tfm" else 20               # tfm needs E == D (encoder.py:121,135)
+                dump_pair(tmp, f"pair_{ne}_{ue}", ne, ue, V=131, E=E, D=D, H=4, T=8, L=5, K=2, B=3,
+                          Nn=23, seed=seed)
+                seed += 1
+        # NRMS shape (BASELINE config 2) at a tiny batch: 300-d, 12 heads (dh=25), T=32, L=50, K=4
+        dump_pair(tmp, "nrms300_tfm_tfm", "tfm", "tfm", V=997, E=300, D=300, H=12, T=32, L=50, K=4, B=2,
+                  Nn=61, seed=300, big=True)
+        # main.twotower defaults (config 1 family): CNN + GRU, E != D allowed
+        dump_pair(tmp, "cnn_rnn_mid", "cnn", "rnn", V=499, E=64, D=96, H=12, T=32, L=50, K=4, B=2,
+                  Nn=41, seed=301, big=True)
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
+if __name__ == "__main__":
+    main()
