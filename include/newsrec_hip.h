@@ -1,0 +1,168 @@
+/*
+ * newsrec_hip.h — C ABI of libnewsrec_hip.so: the MI355X (gfx950) kernels behind the two-tower
+ * hot path of namespace-Pt/News-Recommendation.
+ *
+ * The reference has no FFI layer: its boundary is Python (torch modules).  Each entry point
+ * below replaces the torch-op sequence at the cited reference lines (paths relative to the
+ * reference's src/).  The reference-side binding is the ctypes stub shown in INTEGRATION.md;
+ * the product's own binding is news-recommendation_amd/newsrec_hip/_lib.py.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless the name says host; fp32 = float, ids/masks/labels = int64
+ *     (the dtypes the reference's batches carry, utils/dataset.py:95-103,134-150)
+ *   - all matrices are dense row-major; outputs and workspaces are caller-allocated, nothing is
+ *     allocated, freed or retained by the library (safe under the caller's caching allocator)
+ *   - `stream` is a hipStream_t (pass torch.cuda.current_stream().cuda_stream); every call is
+ *     asynchronous on it; the library keeps no global mutable state except the opt-in profiler
+ *   - return value: 0 = NR_OK, otherwise an NR_ERR_* code; nr_last_error() gives the message
+ *     (thread-local).  Kernels never run on a non-zero return.
+ *   - dropout: keep-mask stream is philox4x32-10(key=seed, counter=(element_index>>2, site)),
+ *     element kept iff u32[element_index & 3] >= p * 2^32, kept values scaled by 1/(1-p)
+ *     (torch's own Philox stream depends on its launch geometry and cannot be reproduced; parity
+ *     tests inject this mask into the oracle).  p = 0 selects eval mode.
+ */
+#ifndef NEWSREC_HIP_H
+#define NEWSREC_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NR_OK 0
+#define NR_ERR_ARG 1          /* bad pointer / size */
+#define NR_ERR_UNSUPPORTED 2  /* shape outside what the kernels are built for */
+#define NR_ERR_LAUNCH 3       /* HIP reported a launch error */
+#define NR_ERR_WORKSPACE 4    /* workspace too small */
+
+int nr_version(void);
+const char* nr_last_error(void);
+
+/* ---- profiling (bench.py roofline leg; no counterpart in the reference) --------------------
+ * When enabled, every launch of a kernel family is bracketed by HIP events on its stream.
+ * nr_prof_read synchronises those events, returns the family's summed device time (ms), launch
+ * count and summed algorithmic work (flops for family 0, bytes otherwise) and clears them. */
+enum { NR_FAM_GEMM = 0, NR_FAM_GATHER = 1, NR_FAM_ATTN = 2, NR_FAM_LN = 3, NR_FAM_POOL = 4, NR_FAM_SCORE = 5, NR_FAM_MISC = 6, NR_FAM_COUNT = 7 };
+int nr_prof_enable(int on);
+int nr_prof_read(int family, double* ms, int64_t* launches, double* work);
+
+/* ---- (i) token-embedding gather — nn.Embedding lookup, models/modules/encoder.py:52,135 ------
+ * out[r,:] = table[ids[r],:] (bit-exact).  *oob_flag (device int, may be NULL) is set to 1 if any
+ * id is outside [0,V) (such rows read row 0 instead of faulting).
+ * Also used for news_embeddings[his_idx] / [cdd_idx], models/BaseModel.py:214-215. */
+int nr_gather_rows_f32(const float* table, int64_t V, int64_t E, const int64_t* ids, int64_t n, float* out, int* oob_flag, void* stream);
+/* embedding backward (autograd of encoder.py:52): grad_table[ids[r],:] += grad_rows[r,:], rows with
+ * ids[r] == padding_idx skipped (BERT word_embeddings has padding_idx = 0).  grad_table is NOT zeroed. */
+int nr_scatter_add_rows_f32(const float* grad_rows, const int64_t* ids, int64_t n, int64_t E, int64_t V, int64_t padding_idx, float* grad_table, void* stream);
+
+/* ---- dense layers on f32 MFMA — nn.Linear / nn.Conv1d call sites --------------------------------
+ * act: 0 none, 1 relu, 2 gelu(erf), 3 tanh.
+ * y[R,N] = act(x[R,K] . w[N,K]^T + b[N]); for act == 2, z (pre-activation, may be NULL) is also stored.
+ * Replaces attention.py:82-84,110,142,155 and encoder.py:57,141,326 (newsProject/userProject). */
+int nr_linear_fwd_f32(const float* x, const float* w, const float* b, int64_t R, int64_t K, int64_t N, int act, float* y, float* z, void* stream);
+/* dx[R,K] = dy[R,N] . w[N,K], then   mode 0: as is | 1: + aux[R,K] | 2: * gelu'(aux[R,K]) |
+ * 3: (+ aux) masked by aux2 > 0 | 4: masked by aux2 > 0. */
+int nr_linear_bwd_input_f32(const float* dy, const float* w, int64_t R, int64_t N, int64_t K, int mode, const float* aux, const float* aux2, float* dx, void* stream);
+/* dw[N,K] = dy[R,N]^T . x[R,K] ; db[N] = column sums of dy (db may be NULL).  ws: scratch of at
+ * least nr_linear_bwd_weight_ws_bytes(R,N,K) bytes. */
+size_t nr_linear_bwd_weight_ws_bytes(int64_t R, int64_t N, int64_t K);
+int nr_linear_bwd_weight_f32(const float* dy, const float* x, int64_t R, int64_t N, int64_t K, float* dw, float* db, void* ws, size_t ws_bytes, void* stream);
+
+/* Conv1d(E->D, kernel_size=3, padding=1) + bias + ReLU over titles, encoder.py:32-38,55-56, as an
+ * implicit GEMM over x[M*T, E] (no im2col buffer).  w is the torch layout [D,E,3];
+ * wpack: scratch of 2*D*3E floats filled by nr_conv1d_k3_pack (re-run after every weight update). */
+int nr_conv1d_k3_pack(const float* w, int64_t D, int64_t E, float* wpack, void* stream);
+int nr_conv1d_k3_relu_fwd_f32(const float* x, const float* wpack, const float* b, int64_t M, int64_t T, int64_t E, int64_t D, float* y, void* stream);
+/* dy must already be masked by relu (y > 0).  dx (may be NULL) [M*T,E]; dw [D,E,3]; db [D]. */
+size_t nr_conv1d_k3_bwd_ws_bytes(int64_t M, int64_t T, int64_t E, int64_t D);
+int nr_conv1d_k3_bwd_f32(const float* dy, const float* x, const float* wpack, int64_t M, int64_t T, int64_t E, int64_t D, float* dx, float* dw, float* db, void* ws, size_t ws_bytes, void* stream);
+
+/* ---- residual + dropout + LayerNorm — TFMSelfOutput / TFMOutput, attention.py:109-113,154-158 ----
+ * y = LN(drop(h) + x; eps) * gamma + beta.  s_out (may be NULL, may alias h) receives drop(h)+x,
+ * mean/rstd [R] (may be NULL) the row statistics needed by the backward. */
+int nr_add_layernorm_fwd_f32(const float* h, const float* x, const float* gamma, const float* beta, int64_t R, int64_t D, float eps, float p_drop, uint64_t seed, uint32_t site, float* y, float* s_out, float* mean, float* rstd, void* stream);
+/* ds = dLN/ds (also the residual gradient); dh (may be NULL) = dropout-masked ds; dgamma/dbeta [D].
+ * ws: nr_layernorm_bwd_ws_bytes(R,D) bytes. */
+size_t nr_layernorm_bwd_ws_bytes(int64_t R, int64_t D);
+int nr_add_layernorm_bwd_f32(const float* dy, const float* s, const float* mean, const float* rstd, const float* gamma, int64_t R, int64_t D, float p_drop, uint64_t seed, uint32_t site, float* ds, float* dh, float* dgamma, float* dbeta, void* ws, size_t ws_bytes, void* stream);
+
+/* ---- multi-head self-attention core — TFMSelfAttention, attention.py:87-97 ---------------------
+ * qkv [N*S, 3*H*dh] (q | k | v blocks per row), mask [N,S] (1 = real token), ctx [N*S, H*dh].
+ * row_max/row_sum [N,H,S] (may be NULL in eval) are the softmax statistics the backward reuses. */
+int nr_mhsa_fwd_f32(const float* qkv, const int64_t* mask, int64_t N, int64_t S, int64_t H, int64_t dh, float p_drop, uint64_t seed, uint32_t site, float* ctx, float* row_max, float* row_sum, void* stream);
+int nr_mhsa_bwd_f32(const float* qkv, const int64_t* mask, const float* ctx, const float* dctx, const float* row_max, const float* row_sum, int64_t N, int64_t S, int64_t H, int64_t dh, float p_drop, uint64_t seed, uint32_t site, float* dqkv, void* stream);
+
+/* ---- additive ("query") pooling — scaled_dp_attention, attention.py:6-34 -----------------------
+ * out[n,:] = softmax_s(query . key[n,s,:] / sqrt(D) + (1-mask[n,s]) * -1e5) . value[n,s,:]
+ * key/value [nseq,S,D]; if idx != NULL, key and value rows are table[idx[n,s],:] instead (eval:
+ * AttnUserEncoder over cached news vectors).  mask may be NULL (encoder.py:298).  prob [nseq,S] may be NULL. */
+int nr_query_pool_fwd_f32(const float* key, const float* value, const float* table, const int64_t* idx, int64_t table_rows, const float* query, const int64_t* mask, int64_t nseq, int64_t S, int64_t D, float* out, float* prob, void* stream);
+/* tanh_key: key = tanh(pre) and dkeypre is the gradient w.r.t. pre (encoder.py:57,141,326);
+ * key_is_value: key = value = same tensor (encoder.py:298) -> dvalue carries both paths.
+ * dquery [D]; ws: nr_query_pool_bwd_ws_bytes(nseq,D). */
+size_t nr_query_pool_bwd_ws_bytes(int64_t nseq, int64_t D);
+int nr_query_pool_bwd_f32(const float* key, const float* value, const float* query, const float* prob, const float* dout, int64_t nseq, int64_t S, int64_t D, int tanh_key, int key_is_value, float* dkeypre, float* dvalue, float* dquery, void* ws, size_t ws_bytes, void* stream);
+
+/* Sum / Avg user encoders, encoder.py:253,274 (mask ignored).  x [nseq,S,D] or table rows by idx. */
+int nr_seq_reduce_f32(const float* x, const float* table, const int64_t* idx, int64_t table_rows, int64_t nseq, int64_t S, int64_t D, int mean, float* out, void* stream);
+int nr_seq_reduce_bwd_f32(const float* dout, int64_t nseq, int64_t S, int64_t D, int mean, float* dx, void* stream);
+
+/* ---- candidate scoring (+ softmax cross-entropy) — _compute_logits + CrossEntropyLoss,
+ *      models/BaseModel.py:164-175,198-205; with idx: the cached `infer` path, BaseModel.py:212-218 ----
+ * logits[b,c] = cdd[b,c,:] . user[b,:] / sqrt(D); cdd rows are table[idx[b,c],:] when idx != NULL.
+ * If loss != NULL: loss[0] = mean_b(-log_softmax(logits[b])[label[b]]); loss_rows [B] scratch. */
+int nr_score_fwd_f32(const float* cdd, const float* table, const int64_t* idx, int64_t table_rows, const float* user, const int64_t* label, int64_t B, int64_t C, int64_t D, float* logits, float* loss_rows, float* loss, void* stream);
+/* gradients of the mean CE loss, scaled by the device scalar grad_out[0]. */
+int nr_score_ce_bwd_f32(const float* cdd, const float* user, const int64_t* label, const float* logits, const float* grad_out, int64_t B, int64_t C, int64_t D, float* d_cdd, float* d_user, void* stream);
+
+/* backward of the plain logits (models/BaseModel.py:174) for callers that apply their own loss:
+ * d_cdd[b,c,:] = dlogits[b,c]/sqrt(D) * user[b,:] ; d_user[b,:] = sum_c dlogits[b,c]/sqrt(D) * cdd[b,c,:]. */
+int nr_score_bwd_f32(const float* cdd, const float* user, const float* dlogits, int64_t B, int64_t C, int64_t D, float* d_cdd, float* d_user, void* stream);
+
+/* ReLU backward from the saved output (self.Relu in encoder.py:56): out = y > 0 ? dy : 0. */
+int nr_relu_bwd_f32(const float* dy, const float* y, int64_t n, float* out, void* stream);
+
+/* ---- one post-LN transformer layer — TFMLayer, attention.py:161-182 -----------------------------
+ * Fused driver over the kernels above (one C call per layer keeps the host off the critical path).
+ * Weights use the reference's tensors unchanged ([out,in] row-major). */
+typedef struct {
+    const float *wq, *bq, *wk, *bk, *wv, *bv;        /* attention.self.{query,key,value} */
+    const float *wo, *bo, *ln1_g, *ln1_b;            /* attention.output.{dense,LayerNorm} */
+    const float *w1, *b1;                            /* intermediate.dense [4D,D] */
+    const float *w2, *b2, *ln2_g, *ln2_b;            /* output.{dense,LayerNorm}  [D,4D] */
+} nr_tfm_weights;
+typedef struct {
+    float *dwq, *dbq, *dwk, *dbk, *dwv, *dbv, *dwo, *dbo, *dln1_g, *dln1_b, *dw1, *db1, *dw2, *db2, *dln2_g, *dln2_b;
+} nr_tfm_grads;
+/* activations kept for the backward (all caller-allocated; R = N*S rows) */
+typedef struct {
+    float *wqkv;      /* [3D, D] packed q|k|v weight   */
+    float *bqkv;      /* [3D]                          */
+    float *qkv;       /* [R, 3D]                       */
+    float *ctx;       /* [R, D]                        */
+    float *s1;        /* [R, D]  drop(dense(ctx)) + x  */
+    float *y1;        /* [R, D]  attention output      */
+    float *z;         /* [R, 4D] pre-GELU              */
+    float *a;         /* [R, 4D] GELU output           */
+    float *s2;        /* [R, D]  drop(dense(a)) + y1   */
+    float *stats;     /* [4, R]  mean1, rstd1, mean2, rstd2 */
+    float *row_max;   /* [N, H, S]                     */
+    float *row_sum;   /* [N, H, S]                     */
+} nr_tfm_saved;
+/* y [R,D] = TFMLayer(x [N,S,D], mask [N,S]).  p_drop = 0 -> eval.  Dropout sites: site_base+0
+ * (attention probs, attention.py:92), +1 (attention.py:111), +2 (attention.py:156). */
+int nr_tfm_layer_fwd_f32(const float* x, const int64_t* mask, int64_t N, int64_t S, int64_t D, int64_t H, const nr_tfm_weights* w, float p_drop, uint64_t seed, uint32_t site_base, nr_tfm_saved* saved, float* y, void* stream);
+/* dx [R,D] and all parameter gradients (overwritten, not accumulated).
+ * ws: nr_tfm_layer_bwd_ws_bytes(N,S,D) bytes of scratch. */
+size_t nr_tfm_layer_bwd_ws_bytes(int64_t N, int64_t S, int64_t D);
+int nr_tfm_layer_bwd_f32(const float* dy, const float* x, const int64_t* mask, int64_t N, int64_t S, int64_t D, int64_t H, const nr_tfm_weights* w, float p_drop, uint64_t seed, uint32_t site_base, const nr_tfm_saved* saved, nr_tfm_grads* grads, float* dx, void* ws, size_t ws_bytes, void* stream);
+
+/* ---- dense Adam — optim.Adam(lr) in BaseModel.get_optimizer, models/BaseModel.py:45-46 ----------
+ * torch defaults (betas 0.9/0.999, eps 1e-8, no weight decay, no amsgrad); step counts from 1. */
+int nr_adam_step_f32(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr, float beta1, float beta2, float eps, int64_t step, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NEWSREC_HIP_H */

@@ -1,0 +1,262 @@
+// Multi-head self-attention over short sequences (titles S=32, histories S=50; S <= 64),
+// one wave per (sequence, head).  The S x S score tile is tiny (<= 16 KiB), so the whole
+// head lives in LDS/registers: lane i owns query row i (fwd, bwd phase A) or key row j
+// (bwd phase B).  Score arithmetic follows the reference literally:
+//   x_ij = fl32( fl32(q_i . k_j) / sqrt(dh) ) + (1 - mask_j) * (-1e5)      (attention.py:87-90)
+//   p_ij = exp(x_ij - max_j x_ij) / sum_j exp(...)
+// so fully masked rows reproduce the 2^-7 quantisation of `score - 1e5`.
+// ~1-2 % of the layer's flops: plain VALU fma (the f32 MFMA rate equals the f32 VALU rate).
+#include "common.h"
+#include "seqops.h"
+
+namespace nr {
+
+constexpr float MASK_FILL = -1e5f;
+
+// cooperative [S, dh] tile copy global(row stride ld) -> LDS rows of DHP+1 floats (zero padded)
+// LDS row stride LDS_LD: DHP+1 (odd: conflict-free when lane i reads row i) or DHP (16-B aligned
+// rows for broadcast float4 reads of K/V)
+template <int DHP, int LDS_LD>
+__device__ __forceinline__ void tile_to_lds(float* lds, const float* __restrict__ g, int64_t ld, int S, int dh, int lane) {
+    for (int idx = lane; idx < S * DHP; idx += 64) {
+        const int r = idx / DHP, d = idx - r * DHP;
+        lds[r * LDS_LD + d] = (d < dh) ? g[(int64_t)r * ld + d] : 0.f;
+    }
+}
+template <int DHP, int LDS_LD>
+__device__ __forceinline__ void lds_to_tile(float* __restrict__ g, int64_t ld, const float* lds, int S, int dh, int lane) {
+    for (int idx = lane; idx < S * dh; idx += 64) {
+        const int r = idx / dh, d = idx - r * dh;
+        g[(int64_t)r * ld + d] = lds[r * LDS_LD + d];
+    }
+}
+// dot of a register row with a broadcast LDS row (16-B aligned)
+template <int DHP>
+__device__ __forceinline__ float dot_bcast(const float (&q)[DHP], const float* row, float acc) {
+#pragma unroll
+    for (int d = 0; d < DHP; d += 4) {
+        const float4 k = *reinterpret_cast<const float4*>(row + d);
+        acc = fmaf(q[d], k.x, acc); acc = fmaf(q[d + 1], k.y, acc);
+        acc = fmaf(q[d + 2], k.z, acc); acc = fmaf(q[d + 3], k.w, acc);
+    }
+    return acc;
+}
+template <int DHP>
+__device__ __forceinline__ void axpy_bcast(float (&o)[DHP], float a, const float* row) {
+#pragma unroll
+    for (int d = 0; d < DHP; d += 4) {
+        const float4 v = *reinterpret_cast<const float4*>(row + d);
+        o[d] = fmaf(a, v.x, o[d]); o[d + 1] = fmaf(a, v.y, o[d + 1]);
+        o[d + 2] = fmaf(a, v.z, o[d + 2]); o[d + 3] = fmaf(a, v.w, o[d + 3]);
+    }
+}
+
+__device__ __forceinline__ float keep_scale(const DropoutCfg& dc, uint32_t thr, float scale, int64_t row_linear, int S, int j) {
+    // dropout on attention probabilities: element index = row_linear * S + j
+    const uint64_t idx = (uint64_t)(row_linear * S + j);
+    const Philox4 rn = philox4x32_10(dc.seed, idx >> 2, dc.site);
+    return philox_pick(rn, (int)(idx & 3)) >= thr ? scale : 0.f;
+}
+
+template <int DHP>
+__global__ __launch_bounds__(64) void mhsa_fwd_kernel(const float* __restrict__ qkv, const int64_t* __restrict__ mask,
+                                                      float* __restrict__ ctx, float* __restrict__ row_max,
+                                                      float* __restrict__ row_sum, int S, int H, int dh, DropoutCfg dc) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int LD = DHP + 1;
+    float* Ks = smem;                 // [S][DHP]  broadcast reads
+    float* Vs = Ks + S * DHP;
+    float* Qs = Vs + S * DHP;         // [S][LD]   (reused for the output tile)
+    float* Ss = Qs + S * LD;          // [S][S+1]
+    const int lane = threadIdx.x;
+    const int n = blockIdx.x / H, h = blockIdx.x - n * H;
+    const int A = H * dh;
+    const int64_t ld = 3 * (int64_t)A;
+    const float* base = qkv + (int64_t)n * S * ld + h * dh;
+    tile_to_lds<DHP, LD>(Qs, base, ld, S, dh, lane);
+    tile_to_lds<DHP, DHP>(Ks, base + A, ld, S, dh, lane);
+    tile_to_lds<DHP, DHP>(Vs, base + 2 * A, ld, S, dh, lane);
+    __syncthreads();
+
+    const int i = lane;
+    const bool live = i < S;
+    float q[DHP];
+#pragma unroll
+    for (int d = 0; d < DHP; ++d) q[d] = live ? Qs[i * LD + d] : 0.f;
+    const float sq = sqrtf((float)dh);
+    float* srow = Ss + i * (S + 1);
+    float m = -INFINITY;
+    if (live) {
+        for (int j = 0; j < S; ++j) {
+            const float acc = dot_bcast<DHP>(q, Ks + j * DHP, 0.f);
+            float x = acc / sq;
+            x += mask[(int64_t)n * S + j] ? 0.f : MASK_FILL;
+            srow[j] = x;
+            m = fmaxf(m, x);
+        }
+        float sum = 0.f;
+        for (int j = 0; j < S; ++j) {
+            const float e = expf(srow[j] - m);
+            srow[j] = e;
+            sum += e;
+        }
+        if (row_max) {
+            row_max[((int64_t)n * H + h) * S + i] = m;
+            row_sum[((int64_t)n * H + h) * S + i] = sum;
+        }
+        const uint32_t thr = drop_threshold(dc.p);
+        const float scale = dc.p > 0.f ? 1.0f / (1.0f - dc.p) : 1.0f;
+        const int64_t row_linear = ((int64_t)n * H + h) * S + i;
+        float o[DHP];
+#pragma unroll
+        for (int d = 0; d < DHP; ++d) o[d] = 0.f;
+        for (int j = 0; j < S; ++j) {
+            float p = srow[j] / sum;
+            if (dc.p > 0.f) p *= keep_scale(dc, thr, scale, row_linear, S, j);
+            axpy_bcast<DHP>(o, p, Vs + j * DHP);
+        }
+#pragma unroll
+        for (int d = 0; d < DHP; ++d) Qs[i * LD + d] = o[d];   // row i of Qs is only read by lane i
+    }
+    __syncthreads();
+    lds_to_tile<DHP, LD>(ctx + (int64_t)n * S * A + h * dh, A, Qs, S, dh, lane);
+}
+
+// backward: dqkv[:, q|k|v block of head h] from dctx; recomputes p from (qkv, row_max, row_sum)
+template <int DHP>
+__global__ __launch_bounds__(64) void mhsa_bwd_kernel(const float* __restrict__ qkv, const int64_t* __restrict__ mask,
+                                                      const float* __restrict__ ctx, const float* __restrict__ dctx,
+                                                      const float* __restrict__ row_max, const float* __restrict__ row_sum,
+                                                      float* __restrict__ dqkv, int S, int H, int dh, DropoutCfg dc) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int LD = DHP + 1;
+    float* Ks = smem;                 // [S][DHP] broadcast reads
+    float* Vs = Ks + S * DHP;
+    float* Qs = Vs + S * DHP;         // [S][LD]
+    float* Gs = Qs + S * LD;          // dO tile
+    float* Ts = Gs + S * LD;          // staging tile for dq
+    float* Ps = Ts + S * LD;          // [S][S+1] dropped probabilities
+    float* Ds = Ps + S * (S + 1);     // [S][S+1] dS
+    const int lane = threadIdx.x;
+    const int n = blockIdx.x / H, h = blockIdx.x - n * H;
+    const int A = H * dh;
+    const int64_t ld = 3 * (int64_t)A;
+    const float* base = qkv + (int64_t)n * S * ld + h * dh;
+    tile_to_lds<DHP, LD>(Qs, base, ld, S, dh, lane);
+    tile_to_lds<DHP, DHP>(Ks, base + A, ld, S, dh, lane);
+    tile_to_lds<DHP, DHP>(Vs, base + 2 * A, ld, S, dh, lane);
+    tile_to_lds<DHP, LD>(Gs, dctx + (int64_t)n * S * A + h * dh, A, S, dh, lane);
+    __syncthreads();
+
+    const bool live = lane < S;
+    const float sq = sqrtf((float)dh);
+    const uint32_t thr = drop_threshold(dc.p);
+    const float scale = dc.p > 0.f ? 1.0f / (1.0f - dc.p) : 1.0f;
+    // ---- phase A: lane = query row i
+    {
+        const int i = lane;
+        float q[DHP], go[DHP], dq[DHP];
+        float Di = 0.f;
+#pragma unroll
+        for (int d = 0; d < DHP; ++d) {
+            q[d] = live ? Qs[i * LD + d] : 0.f;
+            go[d] = live ? Gs[i * LD + d] : 0.f;
+            dq[d] = 0.f;
+        }
+        if (live) {
+            const float* orow = ctx + ((int64_t)n * S + i) * A + h * dh;
+            for (int d = 0; d < dh; ++d) Di = fmaf(Gs[i * LD + d], orow[d], Di);   // D_i = dO_i . O_i
+            const float m = row_max[((int64_t)n * H + h) * S + i];
+            const float sum = row_sum[((int64_t)n * H + h) * S + i];
+            const int64_t row_linear = ((int64_t)n * H + h) * S + i;
+            for (int j = 0; j < S; ++j) {
+                const float acc = dot_bcast<DHP>(q, Ks + j * DHP, 0.f);
+                const float dpd = dot_bcast<DHP>(go, Vs + j * DHP, 0.f);
+                float x = acc / sq;
+                x += mask[(int64_t)n * S + j] ? 0.f : MASK_FILL;
+                const float p = expf(x - m) / sum;
+                float pd = p;
+                if (dc.p > 0.f) pd *= keep_scale(dc, thr, scale, row_linear, S, j);
+                const float ds = (pd * dpd - p * Di) / sq;
+                Ps[i * (S + 1) + j] = pd;
+                Ds[i * (S + 1) + j] = ds;
+                axpy_bcast<DHP>(dq, ds, Ks + j * DHP);
+            }
+#pragma unroll
+            for (int d = 0; d < DHP; ++d) Ts[i * LD + d] = dq[d];
+        }
+    }
+    __syncthreads();
+    float* dbase = dqkv + (int64_t)n * S * ld + h * dh;
+    lds_to_tile<DHP, LD>(dbase, ld, Ts, S, dh, lane);
+    // ---- phase B: lane = key row j
+    {
+        const int j = lane;
+        float dk[DHP], dv[DHP];
+#pragma unroll
+        for (int d = 0; d < DHP; ++d) { dk[d] = 0.f; dv[d] = 0.f; }
+        if (live) {
+            for (int i = 0; i < S; ++i) {
+                const float ds = Ds[i * (S + 1) + j];
+                const float pd = Ps[i * (S + 1) + j];
+#pragma unroll
+                for (int d = 0; d < DHP; ++d) {
+                    dk[d] = fmaf(ds, Qs[i * LD + d], dk[d]);
+                    dv[d] = fmaf(pd, Gs[i * LD + d], dv[d]);
+                }
+            }
+        }
+        __syncthreads();     // all reads of Qs / Gs done
+        if (live) {
+#pragma unroll
+            for (int d = 0; d < DHP; ++d) { Qs[j * LD + d] = dk[d]; Gs[j * LD + d] = dv[d]; }
+        }
+    }
+    __syncthreads();
+    lds_to_tile<DHP, LD>(dbase + A, ld, Qs, S, dh, lane);
+    lds_to_tile<DHP, LD>(dbase + 2 * A, ld, Gs, S, dh, lane);
+}
+
+static int pick_dhp(int dh) { return dh <= 32 ? 32 : (dh <= 64 ? 64 : (dh <= 128 ? 128 : 0)); }
+
+int mhsa_fwd(const float* qkv, const int64_t* mask, float* ctx, float* row_max, float* row_sum, int64_t N, int S, int H,
+             int dh, DropoutCfg dc, hipStream_t s) {
+    if (N == 0) return NR_OK;
+    NR_UNSUPPORTED(S > 64 || S < 1, "mhsa: sequence length %d not in [1,64]", S);
+    const int dhp = pick_dhp(dh);
+    NR_UNSUPPORTED(dhp == 0, "mhsa: head dim %d > 128", dh);
+    ProfScope prof(FAM_ATTN, s, 4.0 * N * H * S * S * dh);
+    const size_t lds = (size_t)(2 * S * dhp + S * (dhp + 1) + S * (S + 1)) * sizeof(float);
+    const dim3 grid((unsigned)(N * H));
+#define NR_FWD(P)                                                                                                   \
+    do {                                                                                                            \
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mhsa_fwd_kernel<P>),                               \
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                            \
+        hipLaunchKernelGGL(mhsa_fwd_kernel<P>, grid, dim3(64), lds, s, qkv, mask, ctx, row_max, row_sum, S, H, dh, dc); \
+    } while (0)
+    if (dhp == 32) NR_FWD(32); else if (dhp == 64) NR_FWD(64); else NR_FWD(128);
+#undef NR_FWD
+    return check_launch("mhsa_fwd");
+}
+
+int mhsa_bwd(const float* qkv, const int64_t* mask, const float* ctx, const float* dctx, const float* row_max,
+             const float* row_sum, float* dqkv, int64_t N, int S, int H, int dh, DropoutCfg dc, hipStream_t s) {
+    if (N == 0) return NR_OK;
+    NR_UNSUPPORTED(S > 64 || S < 1, "mhsa bwd: sequence length %d not in [1,64]", S);
+    const int dhp = pick_dhp(dh);
+    NR_UNSUPPORTED(dhp == 0 || dhp > 64, "mhsa bwd: head dim %d > 64", dh);
+    ProfScope prof(FAM_ATTN, s, 10.0 * N * H * S * S * dh);
+    const size_t lds = (size_t)(2 * S * dhp + 3 * S * (dhp + 1) + 2 * S * (S + 1)) * sizeof(float);
+    const dim3 grid((unsigned)(N * H));
+#define NR_BWD(P)                                                                                                   \
+    do {                                                                                                            \
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mhsa_bwd_kernel<P>),                               \
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                            \
+        hipLaunchKernelGGL(mhsa_bwd_kernel<P>, grid, dim3(64), lds, s, qkv, mask, ctx, dctx, row_max, row_sum, dqkv, S, H, dh, dc); \
+    } while (0)
+    if (dhp == 32) NR_BWD(32); else NR_BWD(64);
+#undef NR_BWD
+    return check_launch("mhsa_bwd");
+}
+
+}  // namespace nr

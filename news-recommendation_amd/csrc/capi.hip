@@ -1,0 +1,469 @@
+// extern "C" surface of libnewsrec_hip.so (declared in include/newsrec_hip.h) + error/profiler state.
+#include "common.h"
+#include "gemm.h"
+#include "rowops.h"
+#include "seqops.h"
+#include "../../include/newsrec_hip.h"
+
+#include <stdarg.h>
+#include <mutex>
+#include <vector>
+
+namespace nr {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+int check_launch(const char* what) {
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        set_error("%s: %s", what, hipGetErrorString(e));
+        return NR_ERR_LAUNCH;
+    }
+    return NR_OK;
+}
+
+// ---------------------------------------------------------------- profiler
+struct ProfFam {
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> pool;   // reusable event pairs
+    size_t used = 0;
+    double work = 0;
+};
+static bool g_prof_on = false;
+static ProfFam g_fam[FAM_COUNT];
+static std::mutex g_prof_mu;
+
+void prof_begin(int family, hipStream_t s, double work) {
+    if (!g_prof_on) return;
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    ProfFam& f = g_fam[family];
+    if (f.used == f.pool.size()) {
+        hipEvent_t a, b;
+        if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return;
+        f.pool.emplace_back(a, b);
+    }
+    f.work += work;
+    (void)hipEventRecord(f.pool[f.used].first, s);
+}
+void prof_end(int family, hipStream_t s) {
+    if (!g_prof_on) return;
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    ProfFam& f = g_fam[family];
+    if (f.used >= f.pool.size()) return;
+    (void)hipEventRecord(f.pool[f.used].second, s);
+    f.used++;
+}
+
+static inline hipStream_t S(void* s) { return reinterpret_cast<hipStream_t>(s); }
+static inline DropoutCfg DC(float p, uint64_t seed, uint32_t site) {
+    DropoutCfg d; d.p = p; d.seed = seed; d.site = site; return d;
+}
+static inline float* bump(char*& cur, size_t floats) {
+    float* p = reinterpret_cast<float*>(cur);
+    cur += ((floats * sizeof(float) + 255) / 256) * 256;
+    return p;
+}
+static inline size_t pad256(size_t floats) { return ((floats * sizeof(float) + 255) / 256) * 256; }
+
+// y = act(x w^T + b)
+static int linear_fwd(const float* x, int64_t ldx, const float* w, const float* b, int64_t R, int64_t K, int64_t N, int epi,
+                      float* y, float* z, hipStream_t s) {
+    GemmParams p;
+    p.A = x; p.lda = ldx; p.B = w; p.ldb = K; p.C = y; p.ldc = N;
+    p.M = (int)R; p.N = (int)N; p.K = (int)K; p.bias = b; p.epi = epi; p.out2 = z; p.ldout2 = N;
+    return gemm_f32(p, true, true, nullptr, 0, s);
+}
+// dx = dy w  (+ epilogue)
+static int linear_bwd_input(const float* dy, int64_t lddy, const float* w, int64_t R, int64_t N, int64_t K, int epi,
+                            const float* aux, const float* aux2, float* dx, hipStream_t s) {
+    GemmParams p;
+    p.A = dy; p.lda = lddy; p.B = w; p.ldb = K; p.C = dx; p.ldc = K;
+    p.M = (int)R; p.N = (int)K; p.K = (int)N; p.epi = epi; p.aux = aux; p.ldaux = K; p.aux2 = aux2; p.ldaux2 = K;
+    return gemm_f32(p, true, false, nullptr, 0, s);
+}
+static size_t bwd_weight_ws(int64_t R, int64_t N, int64_t K, bool with_bias) {
+    const int ks = choose_ksplit((int)N, (int)K, (int)R);
+    size_t b = pad256(gemm_workspace_bytes((int)N, (int)K, ks) / sizeof(float));
+    if (with_bias) b += pad256((size_t)colsum_chunks(R) * N);
+    return b;
+}
+// dw = dy^T x ; db = colsum(dy)
+static int linear_bwd_weight(const float* dy, int64_t lddy, const float* x, int64_t ldx, int64_t R, int64_t N, int64_t K,
+                             float* dw, float* db, char* ws, size_t ws_bytes, int conv_T, int conv_E, hipStream_t s) {
+    const size_t need = bwd_weight_ws(R, N, K, db != nullptr);
+    if (ws_bytes < need || (!ws && need)) {
+        set_error("linear_bwd_weight: workspace %zu < %zu bytes", ws_bytes, need);
+        return NR_ERR_WORKSPACE;
+    }
+    char* cur = ws;
+    GemmParams p;
+    p.A = dy; p.lda = lddy; p.B = x; p.ldb = ldx; p.C = dw; p.ldc = K;
+    p.M = (int)N; p.N = (int)K; p.K = (int)R;
+    p.ksplit = choose_ksplit((int)N, (int)K, (int)R);
+    if (conv_T > 0) { p.conv_on = 2; p.conv_T = conv_T; p.conv_E = conv_E; }
+    const size_t slab_floats = gemm_workspace_bytes((int)N, (int)K, p.ksplit) / sizeof(float);
+    float* slabs = bump(cur, slab_floats);
+    int rc = gemm_f32(p, false, false, slabs, slab_floats * sizeof(float), s);
+    if (rc != NR_OK) return rc;
+    if (db) {
+        float* part = bump(cur, (size_t)colsum_chunks(R) * N);
+        rc = colsum(dy, lddy, R, (int)N, db, part, s);
+    }
+    return rc;
+}
+
+}  // namespace nr
+
+using namespace nr;
+
+extern "C" {
+
+int nr_version(void) { return 1; }
+const char* nr_last_error(void) { return g_err; }
+
+int nr_prof_enable(int on) {
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    g_prof_on = on != 0;
+    for (auto& f : g_fam) { f.used = 0; f.work = 0; }
+    return NR_OK;
+}
+
+int nr_prof_read(int family, double* ms, int64_t* launches, double* work) {
+    NR_CHECK_ARG(family >= 0 && family < FAM_COUNT, "nr_prof_read: family %d out of range", family);
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    ProfFam& f = g_fam[family];
+    double total = 0;
+    for (size_t i = 0; i < f.used; ++i) {
+        if (hipEventSynchronize(f.pool[i].second) != hipSuccess) continue;
+        float t = 0.f;
+        if (hipEventElapsedTime(&t, f.pool[i].first, f.pool[i].second) == hipSuccess) total += t;
+    }
+    if (ms) *ms = total;
+    if (launches) *launches = (int64_t)f.used;
+    if (work) *work = f.work;
+    f.used = 0; f.work = 0;
+    return NR_OK;
+}
+
+int nr_gather_rows_f32(const float* table, int64_t V, int64_t E, const int64_t* ids, int64_t n, float* out, int* oob_flag, void* stream) {
+    NR_CHECK_ARG(n >= 0 && V > 0 && E > 0, "gather_rows: bad sizes n=%lld V=%lld E=%lld", (long long)n, (long long)V, (long long)E);
+    NR_CHECK_ARG(n == 0 || (table && ids && out), "gather_rows: null pointer");
+    return gather_rows(table, V, (int)E, ids, n, out, oob_flag, S(stream));
+}
+
+int nr_scatter_add_rows_f32(const float* grad_rows, const int64_t* ids, int64_t n, int64_t E, int64_t V, int64_t padding_idx, float* grad_table, void* stream) {
+    NR_CHECK_ARG(n >= 0 && V > 0 && E > 0, "scatter_add_rows: bad sizes");
+    NR_CHECK_ARG(n == 0 || (grad_rows && ids && grad_table), "scatter_add_rows: null pointer");
+    return scatter_add_rows(grad_rows, ids, n, (int)E, V, padding_idx, grad_table, S(stream));
+}
+
+int nr_linear_fwd_f32(const float* x, const float* w, const float* b, int64_t R, int64_t K, int64_t N, int act, float* y, float* z, void* stream) {
+    NR_CHECK_ARG(R >= 0 && K > 0 && N > 0, "linear_fwd: bad sizes");
+    NR_CHECK_ARG(act >= 0 && act <= 3, "linear_fwd: act %d not in 0..3", act);
+    NR_CHECK_ARG(R == 0 || (x && w && y), "linear_fwd: null pointer");
+    return linear_fwd(x, K, w, b, R, K, N, act, y, z, S(stream));
+}
+
+int nr_linear_bwd_input_f32(const float* dy, const float* w, int64_t R, int64_t N, int64_t K, int mode, const float* aux, const float* aux2, float* dx, void* stream) {
+    NR_CHECK_ARG(R >= 0 && K > 0 && N > 0, "linear_bwd_input: bad sizes");
+    NR_CHECK_ARG(R == 0 || (dy && w && dx), "linear_bwd_input: null pointer");
+    int epi;
+    switch (mode) {
+        case 0: epi = EPI_NONE; break;
+        case 1: epi = EPI_ADD_AUX; NR_CHECK_ARG(aux, "linear_bwd_input: mode 1 needs aux"); break;
+        case 2: epi = EPI_MUL_GELU_GRAD; NR_CHECK_ARG(aux, "linear_bwd_input: mode 2 needs aux"); break;
+        case 3: epi = EPI_ADD_AUX_RELUMASK; NR_CHECK_ARG(aux && aux2, "linear_bwd_input: mode 3 needs aux, aux2"); break;
+        case 4: epi = EPI_RELUMASK; NR_CHECK_ARG(aux2, "linear_bwd_input: mode 4 needs aux2"); break;
+        default: set_error("linear_bwd_input: mode %d not in 0..4", mode); return NR_ERR_ARG;
+    }
+    return linear_bwd_input(dy, N, w, R, N, K, epi, aux, aux2, dx, S(stream));
+}
+
+size_t nr_linear_bwd_weight_ws_bytes(int64_t R, int64_t N, int64_t K) { return bwd_weight_ws(R, N, K, true); }
+
+int nr_linear_bwd_weight_f32(const float* dy, const float* x, int64_t R, int64_t N, int64_t K, float* dw, float* db, void* ws, size_t ws_bytes, void* stream) {
+    NR_CHECK_ARG(R >= 0 && K > 0 && N > 0, "linear_bwd_weight: bad sizes");
+    NR_CHECK_ARG(dy && x && dw, "linear_bwd_weight: null pointer");
+    return linear_bwd_weight(dy, N, x, K, R, N, K, dw, db, (char*)ws, ws_bytes, 0, 0, S(stream));
+}
+
+int nr_conv1d_k3_pack(const float* w, int64_t D, int64_t E, float* wpack, void* stream) {
+    NR_CHECK_ARG(w && wpack && D > 0 && E > 0, "conv_pack: bad argument");
+    return conv_pack(w, wpack, wpack + D * 3 * E, (int)D, (int)E, S(stream));
+}
+
+int nr_conv1d_k3_relu_fwd_f32(const float* x, const float* wpack, const float* b, int64_t M, int64_t T, int64_t E, int64_t D, float* y, void* stream) {
+    NR_CHECK_ARG(M >= 0 && T > 0 && E > 0 && D > 0, "conv1d_fwd: bad sizes");
+    NR_CHECK_ARG(M == 0 || (x && wpack && y), "conv1d_fwd: null pointer");
+    GemmParams p;
+    p.A = x - E; p.lda = E; p.B = wpack; p.ldb = 3 * E; p.C = y; p.ldc = D;
+    p.M = (int)(M * T); p.N = (int)D; p.K = (int)(3 * E); p.bias = b; p.epi = EPI_RELU;
+    p.conv_on = 1; p.conv_T = (int)T; p.conv_E = (int)E;
+    return gemm_f32(p, true, true, nullptr, 0, S(stream));
+}
+
+size_t nr_conv1d_k3_bwd_ws_bytes(int64_t M, int64_t T, int64_t E, int64_t D) {
+    return pad256((size_t)D * 3 * E) + bwd_weight_ws(M * T, D, 3 * E, true);
+}
+
+int nr_conv1d_k3_bwd_f32(const float* dy, const float* x, const float* wpack, int64_t M, int64_t T, int64_t E, int64_t D, float* dx, float* dw, float* db, void* ws, size_t ws_bytes, void* stream) {
+    NR_CHECK_ARG(M >= 0 && T > 0 && E > 0 && D > 0, "conv1d_bwd: bad sizes");
+    NR_CHECK_ARG(dy && x && wpack && dw, "conv1d_bwd: null pointer");
+    if (ws_bytes < nr_conv1d_k3_bwd_ws_bytes(M, T, E, D) || !ws) { set_error("conv1d_bwd: workspace too small"); return NR_ERR_WORKSPACE; }
+    hipStream_t s = S(stream);
+    const int64_t R = M * T;
+    if (dx) {
+        GemmParams p;
+        p.A = dy - D; p.lda = D; p.B = wpack + D * 3 * E; p.ldb = 3 * D; p.C = dx; p.ldc = E;
+        p.M = (int)R; p.N = (int)E; p.K = (int)(3 * D);
+        p.conv_on = 1; p.conv_T = (int)T; p.conv_E = (int)D;
+        if (int rc = gemm_f32(p, true, true, nullptr, 0, s)) return rc;
+    }
+    char* cur = (char*)ws;
+    float* gwf = bump(cur, (size_t)D * 3 * E);
+    const size_t rest = ws_bytes - (size_t)(cur - (char*)ws);
+    if (int rc = linear_bwd_weight(dy, D, x - E, E, R, D, 3 * E, gwf, db, cur, rest, (int)T, (int)E, s)) return rc;
+    return conv_unpack_grad(gwf, dw, (int)D, (int)E, s);
+}
+
+int nr_add_layernorm_fwd_f32(const float* h, const float* x, const float* gamma, const float* beta, int64_t R, int64_t D, float eps, float p_drop, uint64_t seed, uint32_t site, float* y, float* s_out, float* mean, float* rstd, void* stream) {
+    NR_CHECK_ARG(R >= 0 && D > 0, "layernorm_fwd: bad sizes");
+    NR_CHECK_ARG(R == 0 || (h && gamma && beta && y), "layernorm_fwd: null pointer");
+    NR_CHECK_ARG(p_drop >= 0.f && p_drop < 1.f, "layernorm_fwd: p_drop %f not in [0,1)", p_drop);
+    return ln_fwd(h, x, gamma, beta, y, s_out, mean, rstd, R, (int)D, eps, DC(p_drop, seed, site), S(stream));
+}
+
+size_t nr_layernorm_bwd_ws_bytes(int64_t R, int64_t D) {
+    return 2 * pad256((size_t)ln_bwd_blocks(R) * D) + pad256((size_t)colsum_chunks(ln_bwd_blocks(R)) * D);
+}
+
+static int layernorm_bwd(const float* dy, const float* s_in, const float* mean, const float* rstd, const float* gamma, int64_t R,
+                         int D, DropoutCfg dc, float* ds, float* dh, float* dgamma, float* dbeta, char* ws, hipStream_t s) {
+    char* cur = ws;
+    const int nb = ln_bwd_blocks(R);
+    float* pg = bump(cur, (size_t)nb * D);
+    float* pb = bump(cur, (size_t)nb * D);
+    float* part = bump(cur, (size_t)colsum_chunks(nb) * D);
+    if (int rc = ln_bwd(dy, s_in, mean, rstd, gamma, ds, dh, pg, pb, R, D, dc, s)) return rc;
+    if (int rc = colsum(pg, D, nb, D, dgamma, part, s)) return rc;
+    return colsum(pb, D, nb, D, dbeta, part, s);
+}
+
+int nr_add_layernorm_bwd_f32(const float* dy, const float* s_in, const float* mean, const float* rstd, const float* gamma, int64_t R, int64_t D, float p_drop, uint64_t seed, uint32_t site, float* ds, float* dh, float* dgamma, float* dbeta, void* ws, size_t ws_bytes, void* stream) {
+    NR_CHECK_ARG(R > 0 && D > 0, "layernorm_bwd: bad sizes");
+    NR_CHECK_ARG(dy && s_in && mean && rstd && gamma && ds && dgamma && dbeta, "layernorm_bwd: null pointer");
+    if (!ws || ws_bytes < nr_layernorm_bwd_ws_bytes(R, D)) { set_error("layernorm_bwd: workspace too small"); return NR_ERR_WORKSPACE; }
+    return layernorm_bwd(dy, s_in, mean, rstd, gamma, R, (int)D, DC(p_drop, seed, site), ds, dh, dgamma, dbeta, (char*)ws, S(stream));
+}
+
+int nr_mhsa_fwd_f32(const float* qkv, const int64_t* mask, int64_t N, int64_t Sq, int64_t H, int64_t dh, float p_drop, uint64_t seed, uint32_t site, float* ctx, float* row_max, float* row_sum, void* stream) {
+    NR_CHECK_ARG(N >= 0 && Sq > 0 && H > 0 && dh > 0, "mhsa_fwd: bad sizes");
+    NR_CHECK_ARG(N == 0 || (qkv && mask && ctx), "mhsa_fwd: null pointer");
+    NR_CHECK_ARG((row_max == nullptr) == (row_sum == nullptr), "mhsa_fwd: row_max/row_sum must both be given or both NULL");
+    return mhsa_fwd(qkv, mask, ctx, row_max, row_sum, N, (int)Sq, (int)H, (int)dh, DC(p_drop, seed, site), S(stream));
+}
+
+int nr_mhsa_bwd_f32(const float* qkv, const int64_t* mask, const float* ctx, const float* dctx, const float* row_max, const float* row_sum, int64_t N, int64_t Sq, int64_t H, int64_t dh, float p_drop, uint64_t seed, uint32_t site, float* dqkv, void* stream) {
+    NR_CHECK_ARG(N >= 0 && Sq > 0 && H > 0 && dh > 0, "mhsa_bwd: bad sizes");
+    NR_CHECK_ARG(N == 0 || (qkv && mask && ctx && dctx && row_max && row_sum && dqkv), "mhsa_bwd: null pointer");
+    return mhsa_bwd(qkv, mask, ctx, dctx, row_max, row_sum, dqkv, N, (int)Sq, (int)H, (int)dh, DC(p_drop, seed, site), S(stream));
+}
+
+int nr_query_pool_fwd_f32(const float* key, const float* value, const float* table, const int64_t* idx, int64_t table_rows, const float* query, const int64_t* mask, int64_t nseq, int64_t Sq, int64_t D, float* out, float* prob, void* stream) {
+    NR_CHECK_ARG(nseq >= 0 && Sq > 0 && D > 0, "query_pool_fwd: bad sizes");
+    NR_CHECK_ARG(nseq == 0 || (query && out), "query_pool_fwd: null pointer");
+    NR_CHECK_ARG(idx ? (table && table_rows > 0) : (key && value), "query_pool_fwd: need key/value or table+idx");
+    return pool_fwd(key, value, table, idx, table_rows, query, mask, out, prob, nseq, (int)Sq, (int)D, S(stream));
+}
+
+size_t nr_query_pool_bwd_ws_bytes(int64_t nseq, int64_t D) {
+    return pad256((size_t)nseq * D) + pad256((size_t)colsum_chunks(nseq) * D);
+}
+
+int nr_query_pool_bwd_f32(const float* key, const float* value, const float* query, const float* prob, const float* dout, int64_t nseq, int64_t Sq, int64_t D, int tanh_key, int key_is_value, float* dkeypre, float* dvalue, float* dquery, void* ws, size_t ws_bytes, void* stream) {
+    NR_CHECK_ARG(nseq > 0 && Sq > 0 && D > 0, "query_pool_bwd: bad sizes");
+    NR_CHECK_ARG(key && value && query && prob && dout && dvalue && dquery && (key_is_value || dkeypre), "query_pool_bwd: null pointer");
+    if (!ws || ws_bytes < nr_query_pool_bwd_ws_bytes(nseq, D)) { set_error("query_pool_bwd: workspace too small"); return NR_ERR_WORKSPACE; }
+    char* cur = (char*)ws;
+    float* dq_part = bump(cur, (size_t)nseq * D);
+    float* part = bump(cur, (size_t)colsum_chunks(nseq) * D);
+    hipStream_t s = S(stream);
+    if (int rc = pool_bwd(key, value, query, prob, dout, dkeypre, dvalue, dq_part, nseq, (int)Sq, (int)D, tanh_key, key_is_value, s)) return rc;
+    return colsum(dq_part, D, nseq, (int)D, dquery, part, s);
+}
+
+int nr_seq_reduce_f32(const float* x, const float* table, const int64_t* idx, int64_t table_rows, int64_t nseq, int64_t Sq, int64_t D, int mean, float* out, void* stream) {
+    NR_CHECK_ARG(nseq >= 0 && Sq > 0 && D > 0, "seq_reduce: bad sizes");
+    NR_CHECK_ARG(nseq == 0 || out, "seq_reduce: null pointer");
+    NR_CHECK_ARG(idx ? (table && table_rows > 0) : (x != nullptr || nseq == 0), "seq_reduce: need x or table+idx");
+    return seq_reduce(x, table, idx, table_rows, out, nseq, (int)Sq, (int)D, mean, S(stream));
+}
+
+int nr_seq_reduce_bwd_f32(const float* dout, int64_t nseq, int64_t Sq, int64_t D, int mean, float* dx, void* stream) {
+    NR_CHECK_ARG(nseq >= 0 && Sq > 0 && D > 0, "seq_reduce_bwd: bad sizes");
+    NR_CHECK_ARG(nseq == 0 || (dout && dx), "seq_reduce_bwd: null pointer");
+    return seq_broadcast(dout, dx, nseq, (int)Sq, (int)D, mean ? 1.0f / (float)Sq : 1.0f, S(stream));
+}
+
+int nr_score_fwd_f32(const float* cdd, const float* table, const int64_t* idx, int64_t table_rows, const float* user, const int64_t* label, int64_t B, int64_t C, int64_t D, float* logits, float* loss_rows, float* loss, void* stream) {
+    NR_CHECK_ARG(B >= 0 && C > 0 && D > 0, "score_fwd: bad sizes");
+    NR_CHECK_ARG(B == 0 || (user && logits), "score_fwd: null pointer");
+    NR_CHECK_ARG(idx ? (table && table_rows > 0) : (cdd != nullptr || B == 0), "score_fwd: need cdd or table+idx");
+    NR_CHECK_ARG(!loss || (loss_rows && label && B > 0), "score_fwd: loss needs loss_rows, label and B > 0");
+    hipStream_t s = S(stream);
+    if (int rc = score_fwd(cdd, table, idx, table_rows, user, label, logits, loss ? loss_rows : nullptr, B, (int)C, (int)D, s)) return rc;
+    if (loss) return mean_f32(loss_rows, (int)B, loss, s);
+    return NR_OK;
+}
+
+int nr_score_ce_bwd_f32(const float* cdd, const float* user, const int64_t* label, const float* logits, const float* grad_out, int64_t B, int64_t C, int64_t D, float* d_cdd, float* d_user, void* stream) {
+    NR_CHECK_ARG(B > 0 && C > 0 && D > 0, "score_ce_bwd: bad sizes");
+    NR_CHECK_ARG(cdd && user && label && logits && grad_out && d_cdd && d_user, "score_ce_bwd: null pointer");
+    return score_bwd(cdd, user, label, logits, grad_out, nullptr, d_cdd, d_user, B, (int)C, (int)D, S(stream));
+}
+
+int nr_score_bwd_f32(const float* cdd, const float* user, const float* dlogits, int64_t B, int64_t C, int64_t D, float* d_cdd, float* d_user, void* stream) {
+    NR_CHECK_ARG(B > 0 && C > 0 && D > 0, "score_bwd: bad sizes");
+    NR_CHECK_ARG(cdd && user && dlogits && d_cdd && d_user, "score_bwd: null pointer");
+    return score_bwd(cdd, user, nullptr, nullptr, nullptr, dlogits, d_cdd, d_user, B, (int)C, (int)D, S(stream));
+}
+
+int nr_relu_bwd_f32(const float* dy, const float* y, int64_t n, float* out, void* stream) {
+    NR_CHECK_ARG(n >= 0 && (n == 0 || (dy && y && out)), "relu_bwd: bad argument");
+    return relu_bwd_f32(dy, y, out, n, S(stream));
+}
+
+int nr_adam_step_f32(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr, float beta1, float beta2, float eps, int64_t step, void* stream) {
+    NR_CHECK_ARG(n >= 0 && step >= 1, "adam_step: bad sizes");
+    NR_CHECK_ARG(n == 0 || (param && grad && exp_avg && exp_avg_sq), "adam_step: null pointer");
+    return adam_f32(param, grad, exp_avg, exp_avg_sq, n, lr, beta1, beta2, eps, step, S(stream));
+}
+
+// ------------------------------------------------------------------------------------ TFM layer
+static bool contiguous3(const float* a, const float* b, const float* c, size_t n) { return b == a + n && c == b + n; }
+
+static int copy_d2d(void* dst, const void* src, size_t bytes, hipStream_t s) {
+    if (hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, s) != hipSuccess) {
+        set_error("hipMemcpyAsync failed");
+        return NR_ERR_LAUNCH;
+    }
+    return NR_OK;
+}
+
+int nr_tfm_layer_fwd_f32(const float* x, const int64_t* mask, int64_t N, int64_t Sq, int64_t D, int64_t H, const nr_tfm_weights* w, float p_drop, uint64_t seed, uint32_t site_base, nr_tfm_saved* sv, float* y, void* stream) {
+    NR_CHECK_ARG(N >= 0 && Sq > 0 && D > 0 && H > 0, "tfm_layer_fwd: bad sizes");
+    NR_CHECK_ARG(w && sv && x && mask && y, "tfm_layer_fwd: null pointer");
+    NR_CHECK_ARG(D % H == 0, "tfm_layer_fwd: hidden dim %lld not divisible by %lld heads (the reference's dense layers need all_head_size == hidden_dim)", (long long)D, (long long)H);
+    NR_CHECK_ARG(sv->qkv && sv->ctx && sv->s1 && sv->y1 && sv->a && sv->s2, "tfm_layer_fwd: missing activation buffer");
+    NR_CHECK_ARG(p_drop >= 0.f && p_drop < 1.f, "tfm_layer_fwd: p_drop %f not in [0,1)", p_drop);
+    if (N == 0) return NR_OK;
+    hipStream_t s = S(stream);
+    const int64_t R = N * Sq;
+    const size_t DD = (size_t)D * D;
+    const float* wqkv = w->wq;
+    const float* bqkv = w->bq;
+    if (!contiguous3(w->wq, w->wk, w->wv, DD) || !contiguous3(w->bq, w->bk, w->bv, (size_t)D)) {
+        NR_CHECK_ARG(sv->wqkv && sv->bqkv, "tfm_layer_fwd: q/k/v weights are not contiguous and no pack buffer given");
+        const float* ws3[3] = {w->wq, w->wk, w->wv};
+        const float* bs3[3] = {w->bq, w->bk, w->bv};
+        for (int i = 0; i < 3; ++i) {
+            if (int rc = copy_d2d(sv->wqkv + i * DD, ws3[i], DD * sizeof(float), s)) return rc;
+            if (int rc = copy_d2d(sv->bqkv + i * D, bs3[i], D * sizeof(float), s)) return rc;
+        }
+        wqkv = sv->wqkv; bqkv = sv->bqkv;
+    }
+    float* mean1 = sv->stats ? sv->stats : nullptr;
+    float* rstd1 = sv->stats ? sv->stats + R : nullptr;
+    float* mean2 = sv->stats ? sv->stats + 2 * R : nullptr;
+    float* rstd2 = sv->stats ? sv->stats + 3 * R : nullptr;
+    if (int rc = linear_fwd(x, D, wqkv, bqkv, R, D, 3 * D, EPI_NONE, sv->qkv, nullptr, s)) return rc;
+    if (int rc = mhsa_fwd(sv->qkv, mask, sv->ctx, sv->row_max, sv->row_sum, N, (int)Sq, (int)H, (int)(D / H), DC(p_drop, seed, site_base), s)) return rc;
+    if (int rc = linear_fwd(sv->ctx, D, w->wo, w->bo, R, D, D, EPI_NONE, sv->s1, nullptr, s)) return rc;
+    if (int rc = ln_fwd(sv->s1, x, w->ln1_g, w->ln1_b, sv->y1, sv->s1, mean1, rstd1, R, (int)D, 1e-12f, DC(p_drop, seed, site_base + 1), s)) return rc;
+    if (int rc = linear_fwd(sv->y1, D, w->w1, w->b1, R, D, 4 * D, EPI_GELU, sv->a, sv->z, s)) return rc;
+    if (int rc = linear_fwd(sv->a, 4 * D, w->w2, w->b2, R, 4 * D, D, EPI_NONE, sv->s2, nullptr, s)) return rc;
+    return ln_fwd(sv->s2, sv->y1, w->ln2_g, w->ln2_b, y, sv->s2, mean2, rstd2, R, (int)D, 1e-12f, DC(p_drop, seed, site_base + 2), s);
+}
+
+size_t nr_tfm_layer_bwd_ws_bytes(int64_t N, int64_t Sq, int64_t D) {
+    const int64_t R = N * Sq;
+    size_t b = 0;
+    b += 8 * pad256((size_t)R * D);                 // ds2 dh2 dy1 ds1 dh1 dctx + 2 spare
+    b += pad256((size_t)R * 4 * D);                 // dz
+    b += pad256((size_t)R * 3 * D);                 // dqkv
+    b += pad256((size_t)3 * D * D) + pad256((size_t)3 * D);
+    b += nr_layernorm_bwd_ws_bytes(R, D);
+    size_t wmax = bwd_weight_ws(R, D, 4 * D, true);
+    wmax = std::max(wmax, bwd_weight_ws(R, 4 * D, D, true));
+    wmax = std::max(wmax, bwd_weight_ws(R, 3 * D, D, true));
+    wmax = std::max(wmax, bwd_weight_ws(R, D, D, true));
+    return b + wmax;
+}
+
+int nr_tfm_layer_bwd_f32(const float* dy, const float* x, const int64_t* mask, int64_t N, int64_t Sq, int64_t D, int64_t H, const nr_tfm_weights* w, float p_drop, uint64_t seed, uint32_t site_base, const nr_tfm_saved* sv, nr_tfm_grads* g, float* dx, void* ws, size_t ws_bytes, void* stream) {
+    NR_CHECK_ARG(N > 0 && Sq > 0 && D > 0 && H > 0 && D % H == 0, "tfm_layer_bwd: bad sizes");
+    NR_CHECK_ARG(dy && x && mask && w && sv && g && dx, "tfm_layer_bwd: null pointer");
+    NR_CHECK_ARG(sv->qkv && sv->ctx && sv->s1 && sv->y1 && sv->z && sv->a && sv->s2 && sv->stats && sv->row_max && sv->row_sum, "tfm_layer_bwd: missing saved activation");
+    if (!ws || ws_bytes < nr_tfm_layer_bwd_ws_bytes(N, Sq, D)) { set_error("tfm_layer_bwd: workspace too small"); return NR_ERR_WORKSPACE; }
+    hipStream_t s = S(stream);
+    const int64_t R = N * Sq;
+    const size_t DD = (size_t)D * D;
+    char* cur = (char*)ws;
+    float* ds2 = bump(cur, (size_t)R * D);
+    float* dh2 = p_drop > 0.f ? bump(cur, (size_t)R * D) : ds2;
+    float* dy1 = bump(cur, (size_t)R * D);
+    float* ds1 = bump(cur, (size_t)R * D);
+    float* dh1 = p_drop > 0.f ? bump(cur, (size_t)R * D) : ds1;
+    float* dctx = bump(cur, (size_t)R * D);
+    float* dz = bump(cur, (size_t)R * 4 * D);
+    float* dqkv = bump(cur, (size_t)R * 3 * D);
+    float* dwqkv = bump(cur, 3 * DD);
+    float* dbqkv = bump(cur, (size_t)3 * D);
+    char* lnws = cur; cur += nr_layernorm_bwd_ws_bytes(R, D);
+    char* wws = cur;
+    const size_t wws_bytes = ws_bytes - (size_t)(cur - (char*)ws);
+    const float* mean1 = sv->stats, *rstd1 = sv->stats + R, *mean2 = sv->stats + 2 * R, *rstd2 = sv->stats + 3 * R;
+    const float* wqkv = contiguous3(w->wq, w->wk, w->wv, DD) ? w->wq : sv->wqkv;
+    NR_CHECK_ARG(wqkv, "tfm_layer_bwd: q/k/v weights are not contiguous and no packed copy saved");
+
+    // LN2 <- dy
+    if (int rc = layernorm_bwd(dy, sv->s2, mean2, rstd2, w->ln2_g, R, (int)D, DC(p_drop, seed, site_base + 2), ds2,
+                               p_drop > 0.f ? dh2 : nullptr, g->dln2_g, g->dln2_b, lnws, s)) return rc;
+    // FFN2: dW2 = dh2^T a ; dz = (dh2 W2) * gelu'(z)
+    if (int rc = linear_bwd_weight(dh2, D, sv->a, 4 * D, R, D, 4 * D, g->dw2, g->db2, wws, wws_bytes, 0, 0, s)) return rc;
+    if (int rc = linear_bwd_input(dh2, D, w->w2, R, D, 4 * D, EPI_MUL_GELU_GRAD, sv->z, nullptr, dz, s)) return rc;
+    // FFN1: dW1 = dz^T y1 ; dy1 = dz W1 + ds2 (residual)
+    if (int rc = linear_bwd_weight(dz, 4 * D, sv->y1, D, R, 4 * D, D, g->dw1, g->db1, wws, wws_bytes, 0, 0, s)) return rc;
+    if (int rc = linear_bwd_input(dz, 4 * D, w->w1, R, 4 * D, D, EPI_ADD_AUX, ds2, nullptr, dy1, s)) return rc;
+    // LN1
+    if (int rc = layernorm_bwd(dy1, sv->s1, mean1, rstd1, w->ln1_g, R, (int)D, DC(p_drop, seed, site_base + 1), ds1,
+                               p_drop > 0.f ? dh1 : nullptr, g->dln1_g, g->dln1_b, lnws, s)) return rc;
+    // attention output projection
+    if (int rc = linear_bwd_weight(dh1, D, sv->ctx, D, R, D, D, g->dwo, g->dbo, wws, wws_bytes, 0, 0, s)) return rc;
+    if (int rc = linear_bwd_input(dh1, D, w->wo, R, D, D, EPI_NONE, nullptr, nullptr, dctx, s)) return rc;
+    // attention core
+    if (int rc = mhsa_bwd(sv->qkv, mask, sv->ctx, dctx, sv->row_max, sv->row_sum, dqkv, N, (int)Sq, (int)H, (int)(D / H),
+                          DC(p_drop, seed, site_base), s)) return rc;
+    // QKV projection: packed dW [3D, D], db [3D]; dx = dqkv Wqkv + ds1 (residual)
+    const bool gcontig = contiguous3(g->dwq, g->dwk, g->dwv, DD) && contiguous3(g->dbq, g->dbk, g->dbv, (size_t)D);
+    float* dwp = gcontig ? g->dwq : dwqkv;
+    float* dbp = gcontig ? g->dbq : dbqkv;
+    if (int rc = linear_bwd_weight(dqkv, 3 * D, x, D, R, 3 * D, D, dwp, dbp, wws, wws_bytes, 0, 0, s)) return rc;
+    if (!gcontig) {
+        float* dws[3] = {g->dwq, g->dwk, g->dwv};
+        float* dbs[3] = {g->dbq, g->dbk, g->dbv};
+        for (int i = 0; i < 3; ++i) {
+            if (int rc = copy_d2d(dws[i], dwqkv + i * DD, DD * sizeof(float), s)) return rc;
+            if (int rc = copy_d2d(dbs[i], dbqkv + i * D, D * sizeof(float), s)) return rc;
+        }
+    }
+    return linear_bwd_input(dqkv, 3 * D, wqkv, R, 3 * D, D, EPI_ADD_AUX, ds1, nullptr, dx, s);
+}
+
+}  // extern "C"

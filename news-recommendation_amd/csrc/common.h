@@ -1,0 +1,96 @@
+// Shared device/host helpers for the newsrec HIP library (gfx950 / MI355X only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#define NR_OK 0
+#define NR_ERR_ARG 1
+#define NR_ERR_UNSUPPORTED 2
+#define NR_ERR_LAUNCH 3
+#define NR_ERR_WORKSPACE 4
+
+namespace nr {
+
+void set_error(const char* fmt, ...);
+
+#define NR_CHECK_ARG(cond, ...)                 \
+    do {                                        \
+        if (!(cond)) {                          \
+            nr::set_error(__VA_ARGS__);         \
+            return NR_ERR_ARG;                  \
+        }                                       \
+    } while (0)
+
+#define NR_UNSUPPORTED(cond, ...)               \
+    do {                                        \
+        if (cond) {                             \
+            nr::set_error(__VA_ARGS__);         \
+            return NR_ERR_UNSUPPORTED;          \
+        }                                       \
+    } while (0)
+
+int check_launch(const char* what);
+
+// optional per-family kernel timing (bench.py roofline leg); see prof.hip
+enum Family { FAM_GEMM = 0, FAM_GATHER, FAM_ATTN, FAM_LN, FAM_POOL, FAM_SCORE, FAM_MISC, FAM_COUNT };
+void prof_begin(int family, hipStream_t s, double work);
+void prof_end(int family, hipStream_t s);
+
+struct ProfScope {
+    int fam; hipStream_t s;
+    ProfScope(int f, hipStream_t st, double work) : fam(f), s(st) { prof_begin(f, st, work); }
+    ~ProfScope() { prof_end(fam, s); }
+};
+
+static inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
+
+// ---------------------------------------------------------------- device side
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// exact erf GELU and its derivative (torch.nn.functional.gelu default)
+__device__ __forceinline__ float gelu_f(float z) { return 0.5f * z * (1.0f + erff(z * 0.70710678118654752440f)); }
+__device__ __forceinline__ float gelu_grad_f(float z) {
+    const float cdf = 0.5f * (1.0f + erff(z * 0.70710678118654752440f));
+    const float pdf = 0.39894228040143267794f * expf(-0.5f * z * z);
+    return cdf + z * pdf;
+}
+
+// Philox4x32-10, counter-based: one call yields 4 uniform u32.  The dropout
+// stream of this library is DEFINED as philox(key=(seed_lo,seed_hi),
+// counter=(idx_lo, idx_hi, site, 0)); keep = u32 >= p * 2^32.
+struct Philox4 { uint32_t x, y, z, w; };
+__device__ __forceinline__ Philox4 philox4x32_10(uint64_t seed, uint64_t idx, uint32_t site) {
+    uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+    uint32_t c0 = (uint32_t)idx, c1 = (uint32_t)(idx >> 32), c2 = site, c3 = 0u;
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+        const uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+        const uint32_t n0 = hi1 ^ c1 ^ k0, n1 = lo1, n2 = hi0 ^ c3 ^ k1, n3 = lo0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    return Philox4{c0, c1, c2, c3};
+}
+__device__ __forceinline__ uint32_t philox_pick(const Philox4& r, int i) {
+    return i == 0 ? r.x : (i == 1 ? r.y : (i == 2 ? r.z : r.w));
+}
+// keep-threshold for probability p of dropping
+__host__ __device__ __forceinline__ uint32_t drop_threshold(float p) {
+    double t = (double)p * 4294967296.0;
+    if (t < 0) t = 0;
+    if (t > 4294967295.0) t = 4294967295.0;
+    return (uint32_t)t;
+}
+
+}  // namespace nr

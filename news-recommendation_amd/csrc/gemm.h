@@ -1,0 +1,41 @@
+// internal GEMM interface (see gemm.hip)
+#pragma once
+#include "common.h"
+#include <algorithm>
+
+namespace nr {
+
+enum Epilogue {
+    EPI_NONE = 0,              // y = acc + bias
+    EPI_RELU = 1,              // y = relu(acc + bias)
+    EPI_GELU = 2,              // out2 = z = acc + bias ; y = gelu(z)
+    EPI_TANH = 3,              // y = tanh(acc + bias)
+    EPI_ADD_AUX = 4,           // y = acc + bias + aux
+    EPI_MUL_GELU_GRAD = 5,     // y = (acc + bias) * gelu'(aux)
+    EPI_ADD_AUX_RELUMASK = 6,  // y = (acc + bias + aux) * (aux2 > 0)
+    EPI_RELUMASK = 7,          // y = (acc + bias) * (aux2 > 0)
+};
+
+struct GemmParams {
+    const float* A = nullptr;
+    const float* B = nullptr;
+    float* C = nullptr;
+    int M = 0, N = 0, K = 0;
+    int64_t lda = 0, ldb = 0, ldc = 0;
+    const float* bias = nullptr;
+    const float* aux = nullptr;
+    const float* aux2 = nullptr;
+    float* out2 = nullptr;
+    int64_t ldaux = 0, ldaux2 = 0, ldout2 = 0;
+    int epi = EPI_NONE;
+    int conv_on = 0;           // 0 none, 1: A is an im2col view (k-contig), 2: B is one (reduction-major)
+    int conv_T = 0, conv_E = 0;
+    int ksplit = 1;
+    int64_t split_stride = 0;
+};
+
+int gemm_f32(GemmParams p, bool a_kc, bool b_kc, float* workspace, size_t ws_bytes, hipStream_t s);
+size_t gemm_workspace_bytes(int M, int N, int ksplit);
+int choose_ksplit(int M, int N, int K);
+
+}  // namespace nr

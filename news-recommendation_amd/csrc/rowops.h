@@ -1,0 +1,33 @@
+// internal interface of the HBM-bound row kernels (rowops.hip)
+#pragma once
+#include "common.h"
+#include <algorithm>
+#include <math.h>
+
+namespace nr {
+
+struct DropoutCfg {
+    float p = 0.f;        // drop probability; 0 => identity (eval mode)
+    uint64_t seed = 0;    // philox key
+    uint32_t site = 0;    // stream id of this dropout site
+};
+
+int gather_rows(const float* table, int64_t V, int E, const int64_t* ids, int64_t n, float* out, int* oob_flag, hipStream_t s);
+int scatter_add_rows(const float* grad_rows, const int64_t* ids, int64_t n, int E, int64_t V, int64_t padding_idx,
+                     float* grad_table, hipStream_t s);
+int ln_fwd(const float* h, const float* x, const float* gamma, const float* beta, float* y, float* s_out, float* mean,
+           float* rstd, int64_t R, int D, float eps, DropoutCfg dc, hipStream_t s);
+int ln_bwd_blocks(int64_t R);
+int ln_bwd(const float* dy, const float* sin, const float* mean, const float* rstd, const float* gamma, float* ds,
+           float* dh, float* dgamma_part, float* dbeta_part, int64_t R, int D, DropoutCfg dc, hipStream_t s);
+int colsum_chunks(int64_t R);
+int colsum(const float* in, int64_t ld, int64_t R, int N, float* out, float* part, hipStream_t s);
+int conv_pack(const float* w, float* wf, float* wb, int D, int E, hipStream_t s);
+int conv_unpack_grad(const float* gwf, float* gw, int D, int E, hipStream_t s);
+int add_f32(const float* a, const float* b, float* o, int64_t n, hipStream_t s);
+int relu_bwd_f32(const float* dy, const float* y, float* o, int64_t n, hipStream_t s);
+int mean_f32(const float* v, int n, float* out, hipStream_t s);
+int adam_f32(float* p, const float* g, float* m, float* v, int64_t n, float lr, float b1, float b2, float eps, int64_t step,
+             hipStream_t s);
+
+}  // namespace nr

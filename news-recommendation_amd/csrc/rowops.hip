@@ -1,0 +1,458 @@
+// HBM-bound row kernels: embedding gather / scatter-add, residual+dropout+LayerNorm
+// (fwd/bwd), column sums, GELU-free elementwise helpers, Adam.
+// One wave (64 lanes) owns one row; a row is read/written as 16-byte vectors,
+// i.e. every wave instruction touches 1 KiB of one row (coalesced).
+#include "common.h"
+#include "rowops.h"
+
+namespace nr {
+
+constexpr int WAVES_PER_BLOCK = 4;
+
+static inline bool aligned16(const void* a, const void* b = nullptr, const void* c = nullptr, const void* d = nullptr) {
+    return ((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b) | reinterpret_cast<uintptr_t>(c) |
+             reinterpret_cast<uintptr_t>(d)) & 15) == 0;
+}
+
+// ------------------------------------------------------------------ gather
+// out[r, :] = table[ids[r], :]   (bit-exact copy).  4 rows in flight per wave.
+template <int VEC>
+__global__ __launch_bounds__(256) void gather_rows_kernel(const float* __restrict__ table, const int64_t* __restrict__ ids,
+                                                          float* __restrict__ out, int64_t n, int E, int64_t V,
+                                                          int* __restrict__ oob_flag) {
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = (int64_t)blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6);
+    const int64_t nwave = (int64_t)gridDim.x * WAVES_PER_BLOCK;
+    constexpr int RIF = 4;   // rows in flight
+    for (int64_t r0 = wave * RIF; r0 < n; r0 += nwave * RIF) {
+        int64_t id[RIF];
+#pragma unroll
+        for (int k = 0; k < RIF; ++k) {
+            const int64_t r = r0 + k;
+            int64_t v = (r < n) ? ids[r] : 0;
+            if (v < 0 || v >= V) {            // never fault on a bad index: flag it, read row 0
+                if (lane == 0) *oob_flag = 1;
+                v = 0;
+            }
+            id[k] = v;
+        }
+        if (VEC == 4) {
+            const int nv = E >> 2;
+            for (int c = lane; c < nv; c += 64) {
+                float4 v[RIF];
+#pragma unroll
+                for (int k = 0; k < RIF; ++k)
+                    v[k] = reinterpret_cast<const float4*>(table + id[k] * (int64_t)E)[c];
+#pragma unroll
+                for (int k = 0; k < RIF; ++k)
+                    if (r0 + k < n) reinterpret_cast<float4*>(out + (r0 + k) * (int64_t)E)[c] = v[k];
+            }
+        } else {
+            for (int c = lane; c < E; c += 64) {
+#pragma unroll
+                for (int k = 0; k < RIF; ++k)
+                    if (r0 + k < n) out[(r0 + k) * (int64_t)E + c] = table[id[k] * (int64_t)E + c];
+            }
+        }
+    }
+}
+
+int gather_rows(const float* table, int64_t V, int E, const int64_t* ids, int64_t n, float* out, int* oob_flag,
+                hipStream_t s) {
+    if (n == 0) return NR_OK;
+    ProfScope prof(FAM_GATHER, s, 2.0 * n * E * 4 + 8.0 * n);
+    const bool vec = (E % 4 == 0) && ((reinterpret_cast<uintptr_t>(table) | reinterpret_cast<uintptr_t>(out)) % 16 == 0);
+    const int grid = (int)std::min<int64_t>(cdiv(n, WAVES_PER_BLOCK * 4), 8192);
+    if (vec) hipLaunchKernelGGL(gather_rows_kernel<4>, dim3(grid), dim3(256), 0, s, table, ids, out, n, E, V, oob_flag);
+    else     hipLaunchKernelGGL(gather_rows_kernel<1>, dim3(grid), dim3(256), 0, s, table, ids, out, n, E, V, oob_flag);
+    return check_launch("gather_rows");
+}
+
+// grad_table[ids[r], :] += grad_rows[r, :]  (rows with id == padding_idx skipped:
+// nn.Embedding(padding_idx) semantics).  256 contiguous bytes per atomic wave-instruction.
+__global__ __launch_bounds__(256) void scatter_add_rows_kernel(const float* __restrict__ g, const int64_t* __restrict__ ids,
+                                                               float* __restrict__ gt, int64_t n, int E, int64_t V,
+                                                               int64_t padding_idx) {
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = (int64_t)blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6);
+    const int64_t nwave = (int64_t)gridDim.x * WAVES_PER_BLOCK;
+    for (int64_t r = wave; r < n; r += nwave) {
+        const int64_t id = ids[r];
+        if (id == padding_idx || id < 0 || id >= V) continue;
+        const float* src = g + r * (int64_t)E;
+        float* dst = gt + id * (int64_t)E;
+        for (int c = lane; c < E; c += 64) atomicAdd(dst + c, src[c]);
+    }
+}
+
+int scatter_add_rows(const float* grad_rows, const int64_t* ids, int64_t n, int E, int64_t V, int64_t padding_idx,
+                     float* grad_table, hipStream_t s) {
+    if (n == 0) return NR_OK;
+    ProfScope prof(FAM_GATHER, s, 2.0 * n * E * 4);
+    const int grid = (int)std::min<int64_t>(cdiv(n, WAVES_PER_BLOCK), 8192);
+    hipLaunchKernelGGL(scatter_add_rows_kernel, dim3(grid), dim3(256), 0, s, grad_rows, ids, grad_table, n, E, V, padding_idx);
+    return check_launch("scatter_add_rows");
+}
+
+// ------------------------------------------------------------------ LayerNorm
+// y = LN(drop(h) + x) * gamma + beta ; optionally stores s = drop(h) + x (may alias h),
+// mean and rstd.  VEC=4 needs D % 4 == 0.  D <= 64*VEC*MAXIT.
+constexpr int LN_MAXIT = 8;
+
+template <int VEC, int IT>
+__global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ h, const float* __restrict__ x,
+                                                     const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                     float* __restrict__ y, float* s_out, float* __restrict__ mean_out,
+                                                     float* __restrict__ rstd_out, int64_t R, int D, float eps,
+                                                     DropoutCfg dc) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6);
+    if (row >= R) return;
+    const float* hr = h + row * D;
+    const float* xr = x ? x + row * D : nullptr;
+    float v[IT][VEC];
+    const uint32_t thr = drop_threshold(dc.p);
+    const float scale = dc.p > 0.f ? 1.0f / (1.0f - dc.p) : 1.0f;
+    float sum = 0.f;
+#pragma unroll
+    for (int it = 0; it < IT; ++it) {
+        const int c = (it * 64 + lane) * VEC;
+        if (c < D) {
+            float t[VEC];
+            if (VEC == 4) {
+                const float4 a = *reinterpret_cast<const float4*>(hr + c);
+                t[0] = a.x; t[1 % VEC] = a.y; t[2 % VEC] = a.z; t[3 % VEC] = a.w;
+            } else t[0] = hr[c];
+            if (dc.p > 0.f) {
+                if (VEC == 4) {
+                    const Philox4 rn = philox4x32_10(dc.seed, (uint64_t)(row * D + c) >> 2, dc.site);
+#pragma unroll
+                    for (int e = 0; e < VEC; ++e) t[e] = philox_pick(rn, e) >= thr ? t[e] * scale : 0.f;
+                } else {
+                    const uint64_t idx = (uint64_t)(row * D + c);
+                    const Philox4 rn = philox4x32_10(dc.seed, idx >> 2, dc.site);
+                    t[0] = philox_pick(rn, (int)(idx & 3)) >= thr ? t[0] * scale : 0.f;
+                }
+            }
+            if (xr) {
+                if (VEC == 4) {
+                    const float4 b = *reinterpret_cast<const float4*>(xr + c);
+                    t[0] += b.x; t[1 % VEC] += b.y; t[2 % VEC] += b.z; t[3 % VEC] += b.w;
+                } else t[0] += xr[c];
+            }
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) { v[it][e] = t[e]; sum += t[e]; }
+        } else {
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) v[it][e] = 0.f;
+        }
+    }
+    const float mean = wave_sum(sum) / (float)D;
+    float sq = 0.f;
+#pragma unroll
+    for (int it = 0; it < IT; ++it) {
+        const int c = (it * 64 + lane) * VEC;
+        if (c < D) {
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) { const float d = v[it][e] - mean; sq += d * d; }
+        }
+    }
+    const float var = wave_sum(sq) / (float)D;
+    const float rstd = 1.0f / sqrtf(var + eps);
+    if (lane == 0) {
+        if (mean_out) mean_out[row] = mean;
+        if (rstd_out) rstd_out[row] = rstd;
+    }
+#pragma unroll
+    for (int it = 0; it < IT; ++it) {
+        const int c = (it * 64 + lane) * VEC;
+        if (c < D) {
+            float o[VEC];
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) o[e] = (v[it][e] - mean) * rstd * gamma[c + e] + beta[c + e];
+            if (VEC == 4) {
+                *reinterpret_cast<float4*>(y + row * D + c) = make_float4(o[0], o[1 % VEC], o[2 % VEC], o[3 % VEC]);
+                if (s_out) *reinterpret_cast<float4*>(s_out + row * D + c) =
+                    make_float4(v[it][0], v[it][1 % VEC], v[it][2 % VEC], v[it][3 % VEC]);
+            } else {
+                y[row * D + c] = o[0];
+                if (s_out) s_out[row * D + c] = v[it][0];
+            }
+        }
+    }
+}
+
+int ln_fwd(const float* h, const float* x, const float* gamma, const float* beta, float* y, float* s_out, float* mean,
+           float* rstd, int64_t R, int D, float eps, DropoutCfg dc, hipStream_t s) {
+    if (R == 0) return NR_OK;
+    NR_UNSUPPORTED(D > 64 * 4 * LN_MAXIT, "layernorm: D=%d > %d", D, 64 * 4 * LN_MAXIT);
+    ProfScope prof(FAM_LN, s, (double)R * D * 4 * (x ? 4 : 3));
+    const int grid = cdiv(R, WAVES_PER_BLOCK);
+    const bool vec = (D % 4 == 0) && aligned16(h, x, y, s_out);
+#define NR_LN_FWD(V, I) hipLaunchKernelGGL((ln_fwd_kernel<V, I>), dim3(grid), dim3(256), 0, s, h, x, gamma, beta, y, s_out, mean, rstd, R, D, eps, dc)
+    if (vec) {
+        if (D <= 512) NR_LN_FWD(4, 2); else if (D <= 1024) NR_LN_FWD(4, 4); else NR_LN_FWD(4, 8);
+    } else {
+        NR_UNSUPPORTED(D > 64 * 32, "layernorm (unaligned path): D=%d > 2048", D);
+        if (D <= 512) NR_LN_FWD(1, 8); else NR_LN_FWD(1, 32);
+    }
+#undef NR_LN_FWD
+    return check_launch("ln_fwd");
+}
+
+// backward: given dy and the saved pre-LN input s (+mean, rstd):
+//   ds  = rstd * (g - mean(g) - xhat * mean(g*xhat)),  g = dy*gamma   (grad wrt s; also the residual grad)
+//   dh  = keep ? ds/(1-p) : 0                                          (grad wrt the dropped branch, optional)
+//   dgamma_part[blk] += dy*xhat ; dbeta_part[blk] += dy               (reduced by colsum afterwards)
+template <int VEC, int IT>
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ sin,
+                                                     const float* __restrict__ mean_in, const float* __restrict__ rstd_in,
+                                                     const float* __restrict__ gamma, float* __restrict__ ds,
+                                                     float* __restrict__ dh, float* __restrict__ dgamma_part,
+                                                     float* __restrict__ dbeta_part, int64_t R, int D, DropoutCfg dc) {
+    __shared__ float red[WAVES_PER_BLOCK][2][64 * 4 * LN_MAXIT / 4];   // sized for D<=512 via chunks (see below)
+    const int lane = threadIdx.x & 63;
+    const int wid = threadIdx.x >> 6;
+    float ag[IT][VEC], ab[IT][VEC], gm[IT][VEC];
+#pragma unroll
+    for (int it = 0; it < IT; ++it) {
+        const int c = (it * 64 + lane) * VEC;
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+            ag[it][e] = 0.f; ab[it][e] = 0.f;
+            gm[it][e] = (c + e < D) ? gamma[c + e] : 0.f;
+        }
+    }
+    const uint32_t thr = drop_threshold(dc.p);
+    const float scale = dc.p > 0.f ? 1.0f / (1.0f - dc.p) : 1.0f;
+    for (int64_t row = (int64_t)blockIdx.x * WAVES_PER_BLOCK + wid; row < R; row += (int64_t)gridDim.x * WAVES_PER_BLOCK) {
+        const float mean = mean_in[row], rstd = rstd_in[row];
+        float g[IT][VEC], xh[IT][VEC];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int it = 0; it < IT; ++it) {
+            const int c = (it * 64 + lane) * VEC;
+            if (c < D) {
+                float a[VEC], b[VEC];
+                if (VEC == 4) {
+                    const float4 t = *reinterpret_cast<const float4*>(dy + row * D + c);
+                    const float4 u = *reinterpret_cast<const float4*>(sin + row * D + c);
+                    a[0] = t.x; a[1 % VEC] = t.y; a[2 % VEC] = t.z; a[3 % VEC] = t.w;
+                    b[0] = u.x; b[1 % VEC] = u.y; b[2 % VEC] = u.z; b[3 % VEC] = u.w;
+                } else { a[0] = dy[row * D + c]; b[0] = sin[row * D + c]; }
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) {
+                    const float x = (b[e] - mean) * rstd;
+                    const float gg = a[e] * gm[it][e];
+                    xh[it][e] = x; g[it][e] = gg;
+                    s1 += gg; s2 += gg * x;
+                    ag[it][e] += a[e] * x; ab[it][e] += a[e];
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) { xh[it][e] = 0.f; g[it][e] = 0.f; }
+            }
+        }
+        const float c1 = wave_sum(s1) / (float)D;
+        const float c2 = wave_sum(s2) / (float)D;
+#pragma unroll
+        for (int it = 0; it < IT; ++it) {
+            const int c = (it * 64 + lane) * VEC;
+            if (c < D) {
+                float o[VEC], od[VEC];
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) { o[e] = rstd * (g[it][e] - c1 - xh[it][e] * c2); od[e] = o[e]; }
+                if (dh && dc.p > 0.f) {
+                    if (VEC == 4) {
+                        const Philox4 rn = philox4x32_10(dc.seed, (uint64_t)(row * D + c) >> 2, dc.site);
+#pragma unroll
+                        for (int e = 0; e < VEC; ++e) od[e] = philox_pick(rn, e) >= thr ? o[e] * scale : 0.f;
+                    } else {
+                        const uint64_t idx = (uint64_t)(row * D + c);
+                        const Philox4 rn = philox4x32_10(dc.seed, idx >> 2, dc.site);
+                        od[0] = philox_pick(rn, (int)(idx & 3)) >= thr ? o[0] * scale : 0.f;
+                    }
+                }
+                if (VEC == 4) {
+                    *reinterpret_cast<float4*>(ds + row * D + c) = make_float4(o[0], o[1 % VEC], o[2 % VEC], o[3 % VEC]);
+                    if (dh) *reinterpret_cast<float4*>(dh + row * D + c) = make_float4(od[0], od[1 % VEC], od[2 % VEC], od[3 % VEC]);
+                } else {
+                    ds[row * D + c] = o[0];
+                    if (dh) dh[row * D + c] = od[0];
+                }
+            }
+        }
+    }
+    // cross-wave reduction of the per-column partials, 512 columns at a time
+    for (int base = 0; base < D; base += 512) {
+        __syncthreads();
+#pragma unroll
+        for (int it = 0; it < IT; ++it) {
+            const int c = (it * 64 + lane) * VEC;
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) {
+                const int cc = c + e - base;
+                if (cc >= 0 && cc < 512 && c + e < D) { red[wid][0][cc] = ag[it][e]; red[wid][1][cc] = ab[it][e]; }
+            }
+        }
+        __syncthreads();
+        for (int cc = threadIdx.x; cc < 512 && base + cc < D; cc += 256) {
+            float a = 0.f, b = 0.f;
+#pragma unroll
+            for (int w = 0; w < WAVES_PER_BLOCK; ++w) { a += red[w][0][cc]; b += red[w][1][cc]; }
+            dgamma_part[(int64_t)blockIdx.x * D + base + cc] = a;
+            dbeta_part[(int64_t)blockIdx.x * D + base + cc] = b;
+        }
+    }
+}
+
+int ln_bwd_blocks(int64_t R) { return (int)std::min<int64_t>(cdiv(R, WAVES_PER_BLOCK), 1024); }
+
+int ln_bwd(const float* dy, const float* sin, const float* mean, const float* rstd, const float* gamma, float* ds,
+           float* dh, float* dgamma_part, float* dbeta_part, int64_t R, int D, DropoutCfg dc, hipStream_t s) {
+    if (R == 0) return NR_OK;
+    NR_UNSUPPORTED(D > 64 * 4 * LN_MAXIT, "layernorm bwd: D=%d > %d", D, 64 * 4 * LN_MAXIT);
+    ProfScope prof(FAM_LN, s, (double)R * D * 4 * (dh ? 4 : 3));
+    const int grid = ln_bwd_blocks(R);
+    const bool vec = (D % 4 == 0) && aligned16(dy, sin, ds, dh);
+#define NR_LN_BWD(V, I) hipLaunchKernelGGL((ln_bwd_kernel<V, I>), dim3(grid), dim3(256), 0, s, dy, sin, mean, rstd, gamma, ds, dh, dgamma_part, dbeta_part, R, D, dc)
+    if (vec) {
+        if (D <= 512) NR_LN_BWD(4, 2); else if (D <= 1024) NR_LN_BWD(4, 4); else NR_LN_BWD(4, 8);
+    } else {
+        NR_UNSUPPORTED(D > 64 * 32, "layernorm bwd (unaligned path): D=%d > 2048", D);
+        if (D <= 512) NR_LN_BWD(1, 8); else NR_LN_BWD(1, 32);
+    }
+#undef NR_LN_BWD
+    return check_launch("ln_bwd");
+}
+
+// ------------------------------------------------------------------ column sums
+// out[n] (+)= sum_r in[r, n]; two deterministic stages through `part` [nchunk, N].
+__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ in, int64_t ld, float* __restrict__ out,
+                                                     int64_t R, int N, int64_t rows_per_block) {
+    const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
+    const int64_t r1 = min(R, r0 + rows_per_block);
+    for (int c = threadIdx.x; c < N; c += 256) {
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+        int64_t r = r0;
+        for (; r + 3 < r1; r += 4) {
+            a0 += in[r * ld + c]; a1 += in[(r + 1) * ld + c]; a2 += in[(r + 2) * ld + c]; a3 += in[(r + 3) * ld + c];
+        }
+        for (; r < r1; ++r) a0 += in[r * ld + c];
+        out[(int64_t)blockIdx.x * N + c] = (a0 + a1) + (a2 + a3);
+    }
+}
+
+int colsum_chunks(int64_t R) { return (int)std::max<int64_t>(1, std::min<int64_t>(cdiv(R, 64), 1024)); }
+
+int colsum(const float* in, int64_t ld, int64_t R, int N, float* out, float* part, hipStream_t s) {
+    if (N == 0) return NR_OK;
+    ProfScope prof(FAM_MISC, s, (double)R * N * 4);
+    const int nchunk = colsum_chunks(R);
+    if (nchunk == 1 || !part) {
+        hipLaunchKernelGGL(colsum_kernel, dim3(1), dim3(256), 0, s, in, ld, out, R, N, std::max<int64_t>(R, 1));
+        return check_launch("colsum");
+    }
+    const int64_t rpb = cdiv(R, nchunk);
+    hipLaunchKernelGGL(colsum_kernel, dim3(nchunk), dim3(256), 0, s, in, ld, part, R, N, rpb);
+    hipLaunchKernelGGL(colsum_kernel, dim3(1), dim3(256), 0, s, part, (int64_t)N, out, (int64_t)nchunk, N, (int64_t)nchunk);
+    return check_launch("colsum");
+}
+
+// ------------------------------------------------------------------ small elementwise helpers
+// conv weight re-layouts: w[D,E,3] <-> wf[D, 3E] (wf[d][kk*E+e] = w[d][e][kk]); and the
+// flipped/transposed one for dX: wb[e][kk*D+d] = w[d][e][2-kk]
+__global__ void conv_pack_kernel(const float* __restrict__ w, float* __restrict__ wf, float* __restrict__ wb, int D, int E) {
+    const int64_t total = (int64_t)D * E * 3;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int kk = (int)(i % 3);
+        const int e = (int)((i / 3) % E);
+        const int d = (int)(i / (3 * (int64_t)E));
+        const float v = w[i];
+        if (wf) wf[(int64_t)d * 3 * E + kk * E + e] = v;
+        if (wb) wb[(int64_t)e * 3 * D + (2 - kk) * D + d] = v;
+    }
+}
+__global__ void conv_unpack_grad_kernel(const float* __restrict__ gwf, float* __restrict__ gw, int D, int E) {
+    const int64_t total = (int64_t)D * E * 3;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int kk = (int)(i % 3);
+        const int e = (int)((i / 3) % E);
+        const int d = (int)(i / (3 * (int64_t)E));
+        gw[i] = gwf[(int64_t)d * 3 * E + kk * E + e];
+    }
+}
+int conv_pack(const float* w, float* wf, float* wb, int D, int E, hipStream_t s) {
+    const int64_t total = (int64_t)D * E * 3;
+    hipLaunchKernelGGL(conv_pack_kernel, dim3((int)std::min<int64_t>(cdiv(total, 256), 4096)), dim3(256), 0, s, w, wf, wb, D, E);
+    return check_launch("conv_pack");
+}
+int conv_unpack_grad(const float* gwf, float* gw, int D, int E, hipStream_t s) {
+    const int64_t total = (int64_t)D * E * 3;
+    hipLaunchKernelGGL(conv_unpack_grad_kernel, dim3((int)std::min<int64_t>(cdiv(total, 256), 4096)), dim3(256), 0, s, gwf, gw, D, E);
+    return check_launch("conv_unpack_grad");
+}
+
+// out[i] = a[i] + b[i]
+__global__ void add_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ o, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) o[i] = a[i] + b[i];
+}
+int add_f32(const float* a, const float* b, float* o, int64_t n, hipStream_t s) {
+    if (n == 0) return NR_OK;
+    hipLaunchKernelGGL(add_kernel, dim3((int)std::min<int64_t>(cdiv(n, 256), 8192)), dim3(256), 0, s, a, b, o, n);
+    return check_launch("add");
+}
+
+// out[i] = y[i] > 0 ? dy[i] : 0    (ReLU backward from the saved output)
+__global__ void relu_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ y, float* __restrict__ o, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        o[i] = y[i] > 0.f ? dy[i] : 0.f;
+}
+int relu_bwd_f32(const float* dy, const float* y, float* o, int64_t n, hipStream_t s) {
+    if (n == 0) return NR_OK;
+    hipLaunchKernelGGL(relu_bwd_kernel, dim3((int)std::min<int64_t>(cdiv(n, 256), 8192)), dim3(256), 0, s, dy, y, o, n);
+    return check_launch("relu_bwd");
+}
+
+// mean of a short vector (loss over the batch); one block, fixed order
+__global__ __launch_bounds__(256) void mean_kernel(const float* __restrict__ v, int n, float* __restrict__ out) {
+    __shared__ float red[4];
+    float a = 0.f;
+    for (int i = threadIdx.x; i < n; i += 256) a += v[i];
+    a = wave_sum(a);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = a;
+    __syncthreads();
+    if (threadIdx.x == 0) out[0] = ((red[0] + red[1]) + (red[2] + red[3])) / (float)n;
+}
+int mean_f32(const float* v, int n, float* out, hipStream_t s) {
+    hipLaunchKernelGGL(mean_kernel, dim3(1), dim3(256), 0, s, v, n, out);
+    return check_launch("mean");
+}
+
+// ------------------------------------------------------------------ Adam (torch.optim.Adam defaults, dense)
+__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                   float* __restrict__ v, int64_t n, float b1, float b2, float eps,
+                                                   float step_size, float bc2_sqrt) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const float gi = g[i];
+        const float mi = m[i] + (1.0f - b1) * (gi - m[i]);            // exp_avg.lerp_(grad, 1-beta1)
+        const float vi = v[i] * b2 + (1.0f - b2) * gi * gi;           // mul_(beta2).addcmul_(g, g, 1-beta2)
+        const float denom = sqrtf(vi) / bc2_sqrt + eps;
+        p[i] = p[i] - step_size * (mi / denom);                      // addcdiv_(exp_avg, denom, -step_size)
+        m[i] = mi; v[i] = vi;
+    }
+}
+int adam_f32(float* p, const float* g, float* m, float* v, int64_t n, float lr, float b1, float b2, float eps, int64_t step,
+             hipStream_t s) {
+    if (n == 0) return NR_OK;
+    const double bc1 = 1.0 - pow((double)b1, (double)step);
+    const double bc2 = 1.0 - pow((double)b2, (double)step);
+    const float step_size = (float)((double)lr / bc1);
+    const float bc2_sqrt = (float)sqrt(bc2);
+    ProfScope prof(FAM_MISC, s, (double)n * 4 * 7);
+    hipLaunchKernelGGL(adam_kernel, dim3((int)std::min<int64_t>(cdiv(n, 256), 8192)), dim3(256), 0, s, p, g, m, v, n, b1, b2,
+                       eps, step_size, bc2_sqrt);
+    return check_launch("adam");
+}
+
+}  // namespace nr

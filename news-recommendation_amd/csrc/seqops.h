@@ -1,0 +1,25 @@
+// internal interface of the per-sequence kernels (attention.hip, seqops.hip)
+#pragma once
+#include "common.h"
+#include "rowops.h"
+
+namespace nr {
+
+int mhsa_fwd(const float* qkv, const int64_t* mask, float* ctx, float* row_max, float* row_sum, int64_t N, int S, int H,
+             int dh, DropoutCfg dc, hipStream_t s);
+int mhsa_bwd(const float* qkv, const int64_t* mask, const float* ctx, const float* dctx, const float* row_max,
+             const float* row_sum, float* dqkv, int64_t N, int S, int H, int dh, DropoutCfg dc, hipStream_t s);
+
+int pool_fwd(const float* key, const float* value, const float* table, const int64_t* idx, int64_t nrows, const float* query,
+             const int64_t* mask, float* out, float* prob, int64_t nseq, int S, int D, hipStream_t s);
+int pool_bwd(const float* key, const float* value, const float* query, const float* prob, const float* dout, float* dkeypre,
+             float* dvalue, float* dq_part, int64_t nseq, int S, int D, int tanh_key, int key_is_value, hipStream_t s);
+int score_fwd(const float* cdd, const float* table, const int64_t* idx, int64_t nrows, const float* user, const int64_t* label,
+              float* logits, float* loss_b, int64_t B, int C, int D, hipStream_t s);
+int score_bwd(const float* cdd, const float* user, const int64_t* label, const float* logits, const float* grad_out,
+              const float* dlogits, float* d_cdd, float* d_user, int64_t B, int C, int D, hipStream_t s);
+int seq_reduce(const float* x, const float* table, const int64_t* idx, int64_t nrows, float* out, int64_t nseq, int S, int D,
+               int mean, hipStream_t s);
+int seq_broadcast(const float* dout, float* dx, int64_t nseq, int S, int D, float scale, hipStream_t s);
+
+}  // namespace nr

@@ -1,0 +1,241 @@
+"""Model shells of the two-tower path on MI355X.
+
+`BaseModel` (optimizer, dev/test drivers) and `TwoTowerBaseModel` (forward / infer /
+encode_news / _dev / _test) keep the reference's method names and semantics
+(models/BaseModel.py:17-329) with three deliberate, result-preserving changes that
+SURVEY §2a/§8e call for:
+
+  * `forward` fuses `_compute_logits` + `nn.CrossEntropyLoss` into one HIP kernel pair;
+  * `encode_news` shards the corpus rows over the ranks and all-gathers the [Nn, D] cache
+    (every rank ends with the same table the reference's rank-0-encode + broadcast yields);
+  * `_dev` / `_test` gather flat typed tensors instead of pickled python lists.
+
+The one-tower / gating helpers of the reference are outside the two-tower path and are not built.
+"""
+import logging
+import math
+import os
+import subprocess
+
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.distributed as dist
+from tqdm import tqdm
+
+from newsrec_hip import ops
+from utils.util import pack_results, compute_metrics, HipAdam, linear_warmup_lambda
+
+
+class BaseModel(nn.Module):
+    def __init__(self, manager, name):
+        super().__init__()
+        self.his_size = manager.his_size
+        self.sequence_length = manager.sequence_length
+        self.hidden_dim = manager.hidden_dim
+        self.device = manager.device
+        self.rank = manager.rank
+        self.world_size = manager.world_size
+        for k, v in vars(manager).items():
+            if k.startswith("enable"):
+                setattr(self, k, v)
+        self.negative_num = manager.negative_num
+
+        name = name or type(self).__name__
+        self.name = name if manager.verbose is None else "-".join([name, manager.verbose])
+        self.crossEntropy = nn.CrossEntropyLoss()        # kept for API parity; forward() uses the fused kernel
+        self.logger = logging.getLogger(self.name)
+
+    def get_optimizer(self, manager, dataloader_length):
+        """Adam(lr) over every parameter, optional linear warmup/decay (reference BaseModel.py:45-55).
+        The update runs in the HIP Adam kernel; state keys match torch.optim.Adam."""
+        optimizer = HipAdam(self.parameters(), lr=manager.learning_rate)
+        scheduler = None
+        if manager.scheduler == "linear":
+            total_steps = dataloader_length * manager.epochs
+            warmup = round(manager.warmup * total_steps)
+            scheduler = torch.optim.lr_scheduler.LambdaLR(optimizer, linear_warmup_lambda(warmup, total_steps))
+        return optimizer, scheduler
+
+    @torch.no_grad()
+    def dev(self, manager, loaders, log=False):
+        self.eval()
+        labels, preds = self._dev(manager, loaders)
+        metrics = None
+        if self.rank == 0:
+            metrics = compute_metrics(labels, preds, manager.metrics)
+            metrics["main"] = metrics["auc"]
+            self.logger.info(metrics)
+            if log:
+                manager._log(self.name, metrics)
+        if manager.distributed:
+            _barrier(self.device)
+        return metrics
+
+    @torch.no_grad()
+    def test(self, manager, loaders, log=False):
+        """MIND leaderboard file: per impression, 1-based ranks of the candidates by descending
+        score, ties sharing the smallest rank (reference BaseModel.py:126-152)."""
+        self.eval()
+        preds = self._test(manager, loaders)
+        if manager.rank == 0:
+            save_dir = "data/cache/results/{}/{}/{}".format(self.name, manager.scale, os.path.split(manager.checkpoint)[-1])
+            os.makedirs(save_dir, exist_ok=True)
+            save_path = os.path.join(save_dir, "prediction.txt")
+            with open(save_path, "w") as f:
+                for index, pred in enumerate(preds, 1):
+                    a = 1 - np.asarray(pred, dtype=np.float64)              # the reference ranks `1 - score` in float64
+                    ranks = 1 + (a[None, :] < a[:, None]).sum(axis=1)       # == scipy rankdata(a, method="min")
+                    f.write("{} [{}]\n".format(index, ",".join(str(int(r)) for r in ranks)))
+            try:
+                subprocess.run(["zip", "-j", os.path.join(save_dir, "prediction.zip"), save_path], check=False)
+            except OSError:
+                self.logger.warning("Zip Command Not Found! Skip zipping.")
+            self.logger.info("written to prediction at {}!".format(save_path))
+        if manager.distributed:
+            _barrier(self.device)
+
+
+def _barrier(device):
+    if isinstance(device, int):
+        dist.barrier(device_ids=[device])
+    else:
+        dist.barrier()
+
+
+def _gather_to_rank0(t, world_size, rank):
+    """variable-length typed gather: returns the list of every rank's tensor on rank 0 (else None)."""
+    n = torch.tensor([t.shape[0]], dtype=torch.int64, device=t.device)
+    sizes = [torch.zeros_like(n) for _ in range(world_size)]
+    dist.all_gather(sizes, n)
+    sizes = [int(s.item()) for s in sizes]
+    cap = max(sizes)
+    pad = t.new_zeros((cap,) + tuple(t.shape[1:]))
+    pad[:t.shape[0]] = t
+    bufs = [torch.empty_like(pad) for _ in range(world_size)]
+    dist.all_gather(bufs, pad)
+    if rank != 0:
+        return None
+    return [b[:s] for b, s in zip(bufs, sizes)]
+
+
+class TwoTowerBaseModel(BaseModel):
+    """two-tower models: every news vector can be cached once and reused when scoring."""
+
+    def __init__(self, manager, name=None):
+        super().__init__(manager, name)
+
+    # ------------------------------------------------------------------ scoring
+    def _compute_logits(self, cdd_news_repr, user_repr):
+        """[B,C,D] x [B,1,D] -> [B,C] dot products / sqrt(D) (reference BaseModel.py:164-175)."""
+        return ops.score(cdd_news_repr, user_repr)
+
+    def _encode_news(self, x, cdd=True):
+        key = "cdd" if cdd else "his"
+        token_id = x[key + "_token_id"].to(self.device)
+        attn_mask = x[key + "_attn_mask"].to(self.device)
+        return self.newsEncoder(token_id, attn_mask)
+
+    def _encode_user(self, x=None, his_news_embedding=None, his_mask=None):
+        if x is not None:
+            _, his_news_embedding = self._encode_news(x, cdd=False)
+            his_mask = x["his_mask"].to(self.device)
+        return self.userEncoder(his_news_embedding, his_mask=his_mask)
+
+    def forward(self, x):
+        _, cdd_news_embedding = self._encode_news(x)
+        user_embedding = self._encode_user(x)
+        labels = x["label"].to(self.device)
+        loss, _ = ops.score_cross_entropy(cdd_news_embedding, user_embedding, labels)
+        return loss
+
+    # ------------------------------------------------------------------ cached evaluation
+    def infer(self, x):
+        """logits for rows of (cdd_idx [R,Ce], his_idx [R,L], his_mask [R,L]) against the HBM-resident
+        news-vector cache (reference BaseModel.py:208-218).  Candidates are never materialised:
+        the scoring kernel gathers rows of the cache by index (segmented gather-dot)."""
+        cdd_idx = x["cdd_idx"].to(self.device, non_blocking=True)
+        his_idx = x["his_idx"].to(self.device, non_blocking=True)
+        kind = type(self.userEncoder).__name__
+        if kind == "SumUserEncoder":
+            user = ops.seq_reduce_from_table(self.news_embeddings, his_idx, mean=False)
+        elif kind == "AvgUserEncoder":
+            user = ops.seq_reduce_from_table(self.news_embeddings, his_idx, mean=True)
+        elif kind == "AttnUserEncoder":
+            user = ops.pool_from_table(self.news_embeddings, his_idx, self.userEncoder.user_query)
+        else:
+            his = ops.gather_rows(self.news_embeddings, his_idx)
+            user = self._encode_user(his_news_embedding=his, his_mask=x["his_mask"].to(self.device))
+        return ops.score_from_table(self.news_embeddings, cdd_idx, user)
+
+    @torch.no_grad()
+    def encode_news(self, manager, loader_news):
+        """build the [Nn, D] news-vector cache.  Rows are independent, so each rank encodes the
+        contiguous slice round(Nn/ws*r) .. round(Nn/ws*(r+1)) and the slices are all-gathered; the
+        table every rank ends with equals the reference's rank-0 encode + broadcast
+        (BaseModel.py:221-243), which it replaces.  Token ids are read straight from the dataset's
+        [Nn, T] arrays in large chunks (the per-title result does not depend on the chunking)."""
+        ds = loader_news.dataset
+        Nn = len(ds)
+        ws, rank = (self.world_size, self.rank) if manager.distributed else (1, 0)
+        per = Nn / ws
+        lo, hi = round(per * rank), round(per * (rank + 1))
+        local = torch.zeros((hi - lo, self.hidden_dim), dtype=torch.float32, device=self.device)
+        chunk = int(getattr(manager, "encode_chunk", 8192))
+        stop = min(hi, lo + 7 * loader_news.batch_size) if manager.debug else hi      # --debug: first 7 batches only
+        for s in tqdm(range(lo, stop, chunk), ncols=80, desc="Encoding News", disable=self.rank != 0):
+            e = min(stop, s + chunk)
+            x = {"cdd_token_id": torch.from_numpy(ds.token_ids[s:e]), "cdd_attn_mask": torch.from_numpy(ds.attn_masks[s:e])}
+            _, emb = self._encode_news(x)
+            local[s - lo:e - lo] = emb
+        if manager.distributed:
+            cap = max(round(per * (r + 1)) - round(per * r) for r in range(ws))
+            pad = torch.zeros((cap, self.hidden_dim), dtype=torch.float32, device=self.device)
+            pad[:hi - lo] = local
+            gathered = torch.empty((ws * cap, self.hidden_dim), dtype=torch.float32, device=self.device)
+            dist.all_gather_into_tensor(gathered, pad)
+            parts = [gathered[r * cap: r * cap + round(per * (r + 1)) - round(per * r)] for r in range(ws)]
+            self.news_embeddings = torch.cat(parts, 0).contiguous()
+        else:
+            self.news_embeddings = local
+
+    def _predict(self, manager, loader, with_labels):
+        """score this rank's shard; results stay on the device as flat typed tensors until the end."""
+        impr, masks, labels, preds = [], [], [], []
+        for x in tqdm(loader, ncols=80, desc="Predicting", disable=self.rank != 0):
+            preds.append(self.infer(x))
+            impr.append(x["impr_index"])
+            masks.append(x["cdd_mask"])
+            if with_labels:
+                labels.append(x["label"])
+        dev = self.device
+        Ce = manager.impr_size
+        cat = lambda ts, shape, dt: (torch.cat([t.reshape(shape) for t in ts]).to(dev) if ts else torch.zeros(shape, dtype=dt)[:0].to(dev))
+        out = [cat(impr, (-1,), torch.int64).long(), cat(masks, (-1, Ce), torch.bool).bool(), cat(preds, (-1, Ce), torch.float32)]
+        if with_labels:
+            out.append(cat(labels, (-1, Ce), torch.int64).long())
+        if manager.distributed:
+            _barrier(self.device)
+            gathered = [_gather_to_rank0(t.contiguous() if t.dtype != torch.bool else t.to(torch.uint8), self.world_size, self.rank) for t in out]
+            if self.rank != 0:
+                return None
+            out = [torch.cat(g) for g in gathered]
+        return [t.cpu().numpy() for t in out]
+
+    def _dev(self, manager, loaders):
+        self.encode_news(manager, loaders["news"])
+        res = self._predict(manager, loaders["dev"], with_labels=True)
+        if res is None:
+            return [], []
+        impr, masks, preds, labels = res
+        labels, preds = pack_results(impr, masks.astype(np.bool_), labels.astype(np.int32), preds.astype(np.float32))
+        return labels, preds
+
+    def _test(self, manager, loaders):
+        self.encode_news(manager, loaders["news"])
+        res = self._predict(manager, loaders["test"], with_labels=False)
+        if res is None:
+            return []
+        impr, masks, preds = res
+        preds, = pack_results(impr, masks.astype(np.bool_), preds.astype(np.float32))
+        return preds

@@ -1,0 +1,177 @@
+"""News / user encoders selectable from main.twotower, on the MI355X HIP kernels.
+
+Same class names, constructor argument (``manager``), forward signatures and
+parameter names as the reference's models/modules/encoder.py, so its
+checkpoints load and ``main.twotower`` picks them by the same flags.  torch
+modules are parameter containers; all arithmetic goes through newsrec_hip.ops
+(the one exception, by SURVEY §8-a5, is the GRU cell of ``RnnUserEncoder``,
+which stays on torch.nn.GRU / MIOpen this round).
+"""
+import os
+
+import torch
+import torch.nn as nn
+from torch.nn.utils.rnn import pack_padded_sequence
+
+from newsrec_hip import ops
+from .attention import TFMLayer
+
+
+def load_word_embeddings(manager):
+    """the token table of the reference = HF BERT ``embeddings.word_embeddings``
+    (nn.Embedding(vocab, plm_dim, padding_idx=0)), read from the local ``manager.plm_dir``.
+
+    Extension for synthetic runs (bench / tests, no PLM on disk): if the manager carries
+    ``synthetic_plm=True`` a random table of the same shape is created instead.
+    """
+    if getattr(manager, "synthetic_plm", False):
+        emb = nn.Embedding(manager.vocab_size, manager.plm_dim, padding_idx=0)
+        nn.init.normal_(emb.weight, std=0.02)
+        return emb
+    if not os.path.isdir(manager.plm_dir):
+        raise FileNotFoundError(
+            f"PLM directory {manager.plm_dir} not found. This build never downloads models: place a local "
+            "BERT directory there (config.json + weights), or set manager.synthetic_plm = True for synthetic runs.")
+    from transformers import AutoModel
+    return AutoModel.from_pretrained(manager.plm_dir).embeddings.word_embeddings
+
+
+class BaseNewsEncoder(nn.Module):
+    def __init__(self, manager):
+        super().__init__()
+        self.name = type(self).__name__[:-11]       # "CnnNewsEncoder" -> "Cnn"
+
+
+class BaseUserEncoder(nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.name = type(self).__name__[:-11]
+
+
+class _QueryPooled(object):
+    """shared by the encoders that end in tanh-projected single-query pooling."""
+
+    @staticmethod
+    def make(dim):
+        query = nn.Parameter(torch.randn((1, dim), requires_grad=True))
+        nn.init.xavier_normal_(query)
+        proj = nn.Linear(dim, dim)
+        nn.init.xavier_normal_(proj.weight)
+        return query, proj
+
+
+class CnnNewsEncoder(BaseNewsEncoder):
+    """token gather -> Conv1d(k=3,pad=1)+ReLU (implicit f32-MFMA GEMM) -> query pooling."""
+
+    def __init__(self, manager):
+        super().__init__(manager)
+        self.embedding_dim = manager.plm_dim
+        self.embedding = load_word_embeddings(manager)
+        self.cnn = nn.Conv1d(in_channels=self.embedding_dim, out_channels=manager.hidden_dim, kernel_size=3, padding=1)
+        nn.init.xavier_normal_(self.cnn.weight)
+        self.news_query, self.newsProject = _QueryPooled.make(manager.hidden_dim)
+
+    def forward(self, token_id, attn_mask, token_weight=None):
+        shape = token_id.shape
+        T = shape[-1]
+        ids = token_id.reshape(-1, T)
+        mask = attn_mask.reshape(-1, T)
+        emb = ops.embedding(self.embedding.weight, ids, self.embedding.padding_idx)
+        if token_weight is not None:
+            emb = emb * token_weight.reshape(-1, T).unsqueeze(-1)
+        tok = ops.conv1d_k3_relu(emb, self.cnn.weight, self.cnn.bias)
+        news, _ = ops.project_and_pool(tok, self.newsProject.weight, self.newsProject.bias, self.news_query, mask)
+        return tok.view(*shape, -1), news.view(*shape[:-1], -1)
+
+
+class TfmNewsEncoder(BaseNewsEncoder):
+    """token gather -> one fused transformer layer -> query pooling (NRMS-style)."""
+
+    def __init__(self, manager):
+        super().__init__(manager)
+        self.embedding_dim = manager.plm_dim
+        self.embedding = load_word_embeddings(manager)
+        if self.embedding_dim != manager.hidden_dim:
+            raise ValueError(f"TfmNewsEncoder feeds token embeddings ({self.embedding_dim}-d) straight into a "
+                             f"{manager.hidden_dim}-d transformer layer: the two must be equal (as in the reference)")
+        self.transformer = TFMLayer(manager.hidden_dim, manager.head_num, 0.1)
+        self.news_query, self.newsProject = _QueryPooled.make(manager.hidden_dim)
+
+    def forward(self, token_id, attn_mask, token_weight=None):
+        shape = token_id.shape
+        T = shape[-1]
+        ids = token_id.reshape(-1, T)
+        mask = attn_mask.reshape(-1, T)
+        emb = ops.embedding(self.embedding.weight, ids, self.embedding.padding_idx)
+        if token_weight is not None:
+            emb = emb * token_weight.reshape(-1, T).unsqueeze(-1)
+        tok = self.transformer(emb, attention_mask=mask)
+        news, _ = ops.project_and_pool(tok, self.newsProject.weight, self.newsProject.bias, self.news_query, mask)
+        return tok.view(*shape, -1), news.view(*shape[:-1], -1)
+
+
+class AllBertNewsEncoder(BaseNewsEncoder):
+    """12-layer BERT title encoder ([CLS] vector).  BASELINE config 5 — scheduled after the
+    NRMS path; constructing it raises until its bf16-MFMA kernels land."""
+
+    def __init__(self, manager):
+        super().__init__(manager)
+        raise NotImplementedError("AllBertNewsEncoder (-ne bert) is not built yet in the MI355X path; "
+                                  "use -ne cnn or -ne tfm")
+
+
+class RnnUserEncoder(BaseUserEncoder):
+    """final GRU state over the clicked-news vectors (default -ue).  Delegated to torch.nn.GRU
+    (MIOpen) this round — SURVEY §8 a5 / f3 list the persistent HIP GRU as a later row."""
+
+    def __init__(self, manager):
+        super().__init__()
+        self.rnn = nn.GRU(manager.hidden_dim, manager.hidden_dim, batch_first=True)
+        for name, param in self.rnn.named_parameters():
+            if "weight" in name:
+                nn.init.orthogonal_(param)
+
+    def forward(self, news_embedding, his_mask):
+        lens = his_mask.sum(dim=-1).cpu()
+        packed = pack_padded_sequence(news_embedding, lens, batch_first=True, enforce_sorted=False)
+        _, h = self.rnn(packed)
+        return h.transpose(0, 1)
+
+
+class SumUserEncoder(BaseUserEncoder):
+    def __init__(self, manager):
+        super().__init__()
+
+    def forward(self, news_embedding, **kargs):
+        return ops.seq_reduce(news_embedding, mean=False).unsqueeze(-2)
+
+
+class AvgUserEncoder(BaseUserEncoder):
+    def __init__(self, manager):
+        super().__init__()
+
+    def forward(self, news_embedding, **kargs):
+        return ops.seq_reduce(news_embedding, mean=True).unsqueeze(-2)
+
+
+class AttnUserEncoder(BaseUserEncoder):
+    def __init__(self, manager):
+        super().__init__()
+        self.user_query = nn.Parameter(torch.randn((1, manager.hidden_dim), requires_grad=True))
+        nn.init.xavier_normal_(self.user_query)
+
+    def forward(self, news_embedding, **kargs):
+        # key = value = history, no projection and no mask (reference encoder.py:298)
+        return ops.self_pool(news_embedding, self.user_query).unsqueeze(-2)
+
+
+class TfmUserEncoder(BaseUserEncoder):
+    def __init__(self, manager):
+        super().__init__()
+        self.transformer = TFMLayer(manager.hidden_dim, manager.head_num, 0.1)
+        self.user_query, self.userProject = _QueryPooled.make(manager.hidden_dim)
+
+    def forward(self, news_embedding, his_mask):
+        h = self.transformer(news_embedding, attention_mask=his_mask)
+        user, _ = ops.project_and_pool(h, self.userProject.weight, self.userProject.bias, self.user_query, his_mask)
+        return user.unsqueeze(-2)

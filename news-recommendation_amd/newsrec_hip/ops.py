@@ -1,0 +1,522 @@
+"""torch.autograd glue over the C ABI of libnewsrec_hip.so.
+
+torch is plumbing here: device memory (the caching allocator), the current HIP
+stream and autograd's graph.  Every number is produced by the HIP kernels; a
+tensor that is not a contiguous fp32/int64 tensor on a ROCm device is an
+error, not a cue to fall back (there is nothing to fall back to).
+"""
+import ctypes as C
+import math
+
+import torch
+
+from . import _lib
+from ._lib import NewsrecError, TfmWeights, TfmGrads, TfmSaved, check
+
+PAD_ID = 0          # BERT word_embeddings.padding_idx (manager.special_token_ids["[PAD]"])
+LN_EPS = 1e-12      # models/modules/attention.py:106,151 of the reference
+
+
+def lib():
+    return _lib.load()
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _f32(t, name="tensor"):
+    if not isinstance(t, torch.Tensor) or not t.is_cuda:
+        raise NewsrecError(f"{name}: the MI355X HIP path needs a tensor on a ROCm device "
+                           f"(got {type(t).__name__} on {getattr(t, 'device', None)}); there is no CPU path in this package")
+    if t.dtype != torch.float32:
+        raise NewsrecError(f"{name}: expected float32, got {t.dtype}")
+    return t if t.is_contiguous() else t.contiguous()
+
+
+def _i64(t, name="tensor"):
+    if not isinstance(t, torch.Tensor) or not t.is_cuda:
+        raise NewsrecError(f"{name}: the MI355X HIP path needs a tensor on a ROCm device (got {getattr(t, 'device', None)})")
+    if t.dtype == torch.bool:
+        t = t.long()
+    if t.dtype != torch.int64:
+        raise NewsrecError(f"{name}: expected int64, got {t.dtype}")
+    return t if t.is_contiguous() else t.contiguous()
+
+
+def _p(t):
+    return None if t is None else t.data_ptr()
+
+
+def _ws(nbytes, device):
+    return torch.empty(max(int(nbytes), 16) // 4 + 4, dtype=torch.float32, device=device)
+
+
+# ----------------------------------------------------------------------------- dropout stream
+class DropoutStream:
+    """hands out (seed, site) pairs; site increments per dropout site per call so masks
+    differ between layers and steps while staying reproducible from torch.initial_seed()."""
+
+    def __init__(self):
+        self._site = 0
+
+    def next(self, n):
+        s = self._site
+        self._site = (self._site + n) & 0x7FFFFFFF
+        return torch.initial_seed() & 0xFFFFFFFFFFFFFFFF, s
+
+    def reset(self, site=0):
+        self._site = site
+
+
+dropout_stream = DropoutStream()
+
+
+# ----------------------------------------------------------------------------- gather / embedding
+def gather_rows(table, ids):
+    """rows of `table` [V,E] by int64 `ids` [...] -> [..., E] (bit-exact, no autograd)."""
+    table = _f32(table, "table")
+    ids = _i64(ids, "ids")
+    out = torch.empty(*ids.shape, table.shape[1], dtype=torch.float32, device=table.device)
+    check(lib().nr_gather_rows_f32(_p(table), table.shape[0], table.shape[1], _p(ids), ids.numel(), _p(out), None,
+                                   _stream()), "nr_gather_rows_f32")
+    return out
+
+
+class _Embedding(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, table, ids, padding_idx):
+        out = gather_rows(table, ids)
+        ctx.save_for_backward(ids)
+        ctx.shape = table.shape
+        ctx.padding_idx = -1 if padding_idx is None else int(padding_idx)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        (ids,) = ctx.saved_tensors
+        g = _f32(g, "grad")
+        V, E = ctx.shape
+        gt = torch.zeros(V, E, dtype=torch.float32, device=g.device)
+        check(lib().nr_scatter_add_rows_f32(_p(g), _p(ids), ids.numel(), E, V, ctx.padding_idx, _p(gt), _stream()),
+              "nr_scatter_add_rows_f32")
+        return gt, None, None
+
+
+def embedding(table, ids, padding_idx=PAD_ID):
+    """nn.Embedding(padding_idx) forward/backward (encoder.py:52,135 of the reference)."""
+    return _Embedding.apply(_f32(table, "embedding.weight"), _i64(ids, "token_id"), padding_idx)
+
+
+# ----------------------------------------------------------------------------- linear
+ACT = {"none": 0, "relu": 1, "gelu": 2, "tanh": 3}
+
+
+def linear_fwd(x2d, w, b, act="none", z=None):
+    R, K = x2d.shape
+    N = w.shape[0]
+    y = torch.empty(R, N, dtype=torch.float32, device=x2d.device)
+    check(lib().nr_linear_fwd_f32(_p(x2d), _p(w), _p(b), R, K, N, ACT[act], _p(y), _p(z), _stream()), "nr_linear_fwd_f32")
+    return y
+
+
+def linear_bwd_input(dy, w, mode=0, aux=None, aux2=None):
+    R, N = dy.shape
+    K = w.shape[1]
+    dx = torch.empty(R, K, dtype=torch.float32, device=dy.device)
+    check(lib().nr_linear_bwd_input_f32(_p(dy), _p(w), R, N, K, mode, _p(aux), _p(aux2), _p(dx), _stream()),
+          "nr_linear_bwd_input_f32")
+    return dx
+
+
+def linear_bwd_weight(dy, x2d, want_bias=True):
+    R, N = dy.shape
+    K = x2d.shape[1]
+    dw = torch.empty(N, K, dtype=torch.float32, device=dy.device)
+    db = torch.empty(N, dtype=torch.float32, device=dy.device) if want_bias else None
+    nbytes = lib().nr_linear_bwd_weight_ws_bytes(R, N, K)
+    ws = _ws(nbytes, dy.device)
+    check(lib().nr_linear_bwd_weight_f32(_p(dy), _p(x2d), R, N, K, _p(dw), _p(db), _p(ws), ws.numel() * 4, _stream()),
+          "nr_linear_bwd_weight_f32")
+    return dw, db
+
+
+class _Linear(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w, b):
+        x2 = x.reshape(-1, x.shape[-1])
+        y = linear_fwd(x2, w, b)
+        ctx.save_for_backward(x2, w)
+        ctx.has_bias = b is not None
+        ctx.xshape = x.shape
+        return y.view(*x.shape[:-1], w.shape[0])
+
+    @staticmethod
+    def backward(ctx, g):
+        x2, w = ctx.saved_tensors
+        g2 = _f32(g, "grad").reshape(-1, w.shape[0])
+        dx = linear_bwd_input(g2, w).view(ctx.xshape) if ctx.needs_input_grad[0] else None
+        dw, db = linear_bwd_weight(g2, x2, ctx.has_bias)
+        return dx, dw, db
+
+
+def linear(x, w, b=None):
+    return _Linear.apply(_f32(x, "x"), _f32(w, "weight"), None if b is None else _f32(b, "bias"))
+
+
+# ----------------------------------------------------------------------------- conv1d(k=3, pad=1) + relu
+class _ConvRelu(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w, b):
+        # x [M, T, E]; w [D, E, 3]; b [D]
+        M, T, E = x.shape
+        D = w.shape[0]
+        wpack = torch.empty(2 * D * 3 * E, dtype=torch.float32, device=x.device)
+        L = lib()
+        check(L.nr_conv1d_k3_pack(_p(w), D, E, _p(wpack), _stream()), "nr_conv1d_k3_pack")
+        y = torch.empty(M, T, D, dtype=torch.float32, device=x.device)
+        check(L.nr_conv1d_k3_relu_fwd_f32(_p(x), _p(wpack), _p(b), M, T, E, D, _p(y), _stream()),
+              "nr_conv1d_k3_relu_fwd_f32")
+        ctx.save_for_backward(x, wpack, y)
+        ctx.dims = (M, T, E, D)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        x, wpack, y = ctx.saved_tensors
+        M, T, E, D = ctx.dims
+        g = _f32(g, "grad")
+        L = lib()
+        gm = torch.empty_like(g)
+        check(L.nr_relu_bwd_f32(_p(g), _p(y), g.numel(), _p(gm), _stream()), "nr_relu_bwd_f32")
+        dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        dw = torch.empty(D, E, 3, dtype=torch.float32, device=g.device)
+        db = torch.empty(D, dtype=torch.float32, device=g.device)
+        nbytes = L.nr_conv1d_k3_bwd_ws_bytes(M, T, E, D)
+        ws = _ws(nbytes, g.device)
+        check(L.nr_conv1d_k3_bwd_f32(_p(gm), _p(x), _p(wpack), M, T, E, D, _p(dx), _p(dw), _p(db), _p(ws), ws.numel() * 4,
+                                     _stream()), "nr_conv1d_k3_bwd_f32")
+        return dx, dw, db
+
+
+def conv1d_k3_relu(x, w, b):
+    """relu(Conv1d(E->D, 3, padding=1)(x^T))^T on token-major x [M,T,E] (encoder.py:55-56)."""
+    return _ConvRelu.apply(_f32(x, "x"), _f32(w, "cnn.weight"), _f32(b, "cnn.bias"))
+
+
+# ----------------------------------------------------------------------------- transformer layer
+_TFM_ORDER = ("wq", "bq", "wk", "bk", "wv", "bv", "wo", "bo", "ln1_g", "ln1_b", "w1", "b1", "w2", "b2", "ln2_g", "ln2_b")
+
+
+def _carve(device, sizes):
+    """one allocation, 256-B aligned views (floats)."""
+    offs, tot = [], 0
+    for s in sizes:
+        offs.append(tot)
+        tot += (int(s) + 63) // 64 * 64
+    buf = torch.empty(max(tot, 64), dtype=torch.float32, device=device)
+    return buf, [buf[o:o + int(s)] for o, s in zip(offs, sizes)]
+
+
+class _TFMLayer(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, mask, H, p, seed, site, *params):
+        N, S, D = x.shape
+        R = N * S
+        train = any(ctx.needs_input_grad)       # False under no_grad / eval-only calls
+        sizes = [3 * D * D, 3 * D, R * 3 * D, R * D, R * D, R * D, R * 4 * D if train else 0, R * 4 * D, R * D,
+                 4 * R if train else 0, N * H * S if train else 0, N * H * S if train else 0]
+        buf, (wqkv, bqkv, qkv, cx, s1, y1, z, a, s2, stats, rmax, rsum) = _carve(x.device, sizes)
+        y = torch.empty(N, S, D, dtype=torch.float32, device=x.device)
+        W = TfmWeights(*[_p(t) for t in params])
+        SV = TfmSaved(_p(wqkv), _p(bqkv), _p(qkv), _p(cx), _p(s1), _p(y1), _p(z) if train else None, _p(a), _p(s2),
+                      _p(stats) if train else None, _p(rmax) if train else None, _p(rsum) if train else None)
+        check(lib().nr_tfm_layer_fwd_f32(_p(x), _p(mask), N, S, D, H, C.byref(W), p, seed, site, C.byref(SV), _p(y),
+                                        _stream()), "nr_tfm_layer_fwd_f32")
+        if train:
+            ctx.save_for_backward(x, mask, buf, *params)
+            ctx.cfg = (N, S, D, H, p, seed, site, sizes)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        x, mask, buf, *params = ctx.saved_tensors
+        N, S, D, H, p, seed, site, sizes = ctx.cfg
+        g = _f32(g, "grad")
+        offs, tot = [], 0
+        for s in sizes:
+            offs.append(tot)
+            tot += (int(s) + 63) // 64 * 64
+        ptrs = [buf.data_ptr() + 4 * o for o in offs]
+        W = TfmWeights(*[_p(t) for t in params])
+        SV = TfmSaved(*ptrs)
+        # packed q|k|v gradient: three contiguous views, handed out as the three parameters' grads
+        gqkv_w = torch.empty(3, D, D, dtype=torch.float32, device=g.device)
+        gqkv_b = torch.empty(3, D, dtype=torch.float32, device=g.device)
+        grads = {n: torch.empty_like(t) for n, t in zip(_TFM_ORDER, params) if n not in ("wq", "wk", "wv", "bq", "bk", "bv")}
+        grads.update(wq=gqkv_w[0], wk=gqkv_w[1], wv=gqkv_w[2], bq=gqkv_b[0], bk=gqkv_b[1], bv=gqkv_b[2])
+        G = TfmGrads(*[_p(grads[n]) for n in _TFM_ORDER])
+        dx = torch.empty_like(x)
+        L = lib()
+        nbytes = L.nr_tfm_layer_bwd_ws_bytes(N, S, D)
+        ws = _ws(nbytes, g.device)
+        check(L.nr_tfm_layer_bwd_f32(_p(g), _p(x), _p(mask), N, S, D, H, C.byref(W), p, seed, site, C.byref(SV), C.byref(G),
+                                     _p(dx), _p(ws), ws.numel() * 4, _stream()), "nr_tfm_layer_bwd_f32")
+        return (dx, None, None, None, None, None) + tuple(grads[n] for n in _TFM_ORDER)
+
+
+def tfm_layer(x, mask, head_num, params, p_drop=0.0, seed=0, site=0):
+    """TFMLayer.forward (attention.py:173-182).  x [N,S,D] fp32, mask [N,S] int64 (1 = real),
+    params: dict with keys wq,bq,wk,bk,wv,bv,wo,bo,ln1_g,ln1_b,w1,b1,w2,b2,ln2_g,ln2_b."""
+    x = _f32(x, "hidden_states")
+    mask = _i64(mask, "attention_mask")
+    if x.dim() != 3 or mask.shape != x.shape[:2]:
+        raise NewsrecError(f"tfm_layer: x {tuple(x.shape)} / mask {tuple(mask.shape)} shape mismatch")
+    plist = [_f32(params[n], n) for n in _TFM_ORDER]
+    D = x.shape[-1]
+    for n, t in zip(_TFM_ORDER, plist):
+        want = {"w1": (4 * D, D), "b1": (4 * D,), "w2": (D, 4 * D)}.get(n, (D, D) if n.startswith("w") else (D,))
+        if tuple(t.shape) != want:
+            raise NewsrecError(f"tfm_layer: parameter {n} has shape {tuple(t.shape)}, expected {want}")
+    return _TFMLayer.apply(x, mask, int(head_num), float(p_drop), int(seed), int(site), *plist)
+
+
+# ----------------------------------------------------------------------------- projection + query pooling
+class _ProjPool(torch.autograd.Function):
+    """out = softmax(q . tanh(x W^T + b)^T / sqrt(D) + mask) . x  — encoder.py:57,141,326."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, query, mask):
+        nseq, S, D = x.shape
+        x2 = x.view(-1, D)
+        key = linear_fwd(x2, w, b, "tanh")
+        out = torch.empty(nseq, D, dtype=torch.float32, device=x.device)
+        prob = torch.empty(nseq, S, dtype=torch.float32, device=x.device)
+        check(lib().nr_query_pool_fwd_f32(_p(key), _p(x), None, None, 0, _p(query), _p(mask), nseq, S, D, _p(out), _p(prob),
+                                          _stream()), "nr_query_pool_fwd_f32")
+        ctx.save_for_backward(x, w, query, key, prob)
+        ctx.mark_non_differentiable(prob)
+        return out, prob
+
+    @staticmethod
+    def backward(ctx, g, _gprob):
+        x, w, query, key, prob = ctx.saved_tensors
+        nseq, S, D = x.shape
+        g = _f32(g, "grad")
+        L = lib()
+        dkeypre = torch.empty(nseq * S, D, dtype=torch.float32, device=g.device)
+        dvalue = torch.empty(nseq * S, D, dtype=torch.float32, device=g.device)
+        dq = torch.empty_like(query)
+        ws = _ws(L.nr_query_pool_bwd_ws_bytes(nseq, D), g.device)
+        check(L.nr_query_pool_bwd_f32(_p(key), _p(x), _p(query), _p(prob), _p(g), nseq, S, D, 1, 0, _p(dkeypre), _p(dvalue),
+                                      _p(dq), _p(ws), ws.numel() * 4, _stream()), "nr_query_pool_bwd_f32")
+        dx = linear_bwd_input(dkeypre, w, 1, dvalue).view(nseq, S, D)       # dkeypre W + dvalue
+        dw, db = linear_bwd_weight(dkeypre, x.view(-1, D))
+        return dx, dw, db, dq, None
+
+
+def project_and_pool(x, w, b, query, mask):
+    """x [nseq,S,D] -> (pooled [nseq,D], prob [nseq,S])."""
+    return _ProjPool.apply(_f32(x, "x"), _f32(w, "project.weight"), _f32(b, "project.bias"), _f32(query, "query"),
+                           _i64(mask, "mask"))
+
+
+class _Pool(torch.autograd.Function):
+    """generic scaled_dp_attention with one query (attention.py:6-34): separate key / value tensors."""
+
+    @staticmethod
+    def forward(ctx, key, value, query, mask):
+        nseq, S, D = key.shape
+        out = torch.empty(nseq, D, dtype=torch.float32, device=key.device)
+        prob = torch.empty(nseq, S, dtype=torch.float32, device=key.device)
+        check(lib().nr_query_pool_fwd_f32(_p(key), _p(value), None, None, 0, _p(query), _p(mask), nseq, S, D, _p(out),
+                                          _p(prob), _stream()), "nr_query_pool_fwd_f32")
+        ctx.save_for_backward(key, value, query, prob)
+        ctx.mark_non_differentiable(prob)
+        return out, prob
+
+    @staticmethod
+    def backward(ctx, g, _gprob):
+        key, value, query, prob = ctx.saved_tensors
+        nseq, S, D = key.shape
+        g = _f32(g, "grad")
+        L = lib()
+        dkey = torch.empty_like(key)
+        dvalue = torch.empty_like(value)
+        dq = torch.empty_like(query)
+        ws = _ws(L.nr_query_pool_bwd_ws_bytes(nseq, D), g.device)
+        check(L.nr_query_pool_bwd_f32(_p(key), _p(value), _p(query), _p(prob), _p(g), nseq, S, D, 0, 0, _p(dkey), _p(dvalue),
+                                      _p(dq), _p(ws), ws.numel() * 4, _stream()), "nr_query_pool_bwd_f32")
+        return dkey, dvalue, dq, None
+
+
+def query_pool(key, value, query, mask=None):
+    """-> (out [nseq,D], prob [nseq,S]); key/value [nseq,S,D], query [1,D] or [D], mask [nseq,S] or None."""
+    key, value, query = _f32(key, "key"), _f32(value, "value"), _f32(query, "query")
+    if key.shape != value.shape:
+        raise NewsrecError("query_pool: this build pools values of the key's width only")
+    return _Pool.apply(key, value, query, None if mask is None else _i64(mask, "attn_mask"))
+
+
+class _SelfPool(torch.autograd.Function):
+    """AttnUserEncoder: key = value = x, no projection, no mask (encoder.py:298)."""
+
+    @staticmethod
+    def forward(ctx, x, query):
+        nseq, S, D = x.shape
+        out = torch.empty(nseq, D, dtype=torch.float32, device=x.device)
+        prob = torch.empty(nseq, S, dtype=torch.float32, device=x.device)
+        check(lib().nr_query_pool_fwd_f32(_p(x), _p(x), None, None, 0, _p(query), None, nseq, S, D, _p(out), _p(prob),
+                                          _stream()), "nr_query_pool_fwd_f32")
+        ctx.save_for_backward(x, query, prob)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        x, query, prob = ctx.saved_tensors
+        nseq, S, D = x.shape
+        g = _f32(g, "grad")
+        L = lib()
+        dx = torch.empty_like(x)
+        dq = torch.empty_like(query)
+        ws = _ws(L.nr_query_pool_bwd_ws_bytes(nseq, D), g.device)
+        check(L.nr_query_pool_bwd_f32(_p(x), _p(x), _p(query), _p(prob), _p(g), nseq, S, D, 0, 1, None, _p(dx), _p(dq),
+                                      _p(ws), ws.numel() * 4, _stream()), "nr_query_pool_bwd_f32")
+        return dx, dq
+
+
+def self_pool(x, query):
+    return _SelfPool.apply(_f32(x, "x"), _f32(query, "query"))
+
+
+def pool_from_table(table, idx, query):
+    """AttnUserEncoder over cached news vectors: rows table[idx[n,s]] (eval only, no autograd)."""
+    table, idx, query = _f32(table, "news_embeddings"), _i64(idx, "his_idx"), _f32(query, "query")
+    nseq, S = idx.shape
+    D = table.shape[1]
+    out = torch.empty(nseq, D, dtype=torch.float32, device=table.device)
+    check(lib().nr_query_pool_fwd_f32(None, None, _p(table), _p(idx), table.shape[0], _p(query), None, nseq, S, D, _p(out),
+                                      None, _stream()), "nr_query_pool_fwd_f32")
+    return out
+
+
+class _SeqReduce(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, mean):
+        nseq, S, D = x.shape
+        out = torch.empty(nseq, D, dtype=torch.float32, device=x.device)
+        check(lib().nr_seq_reduce_f32(_p(x), None, None, 0, nseq, S, D, int(mean), _p(out), _stream()), "nr_seq_reduce_f32")
+        ctx.dims = (nseq, S, D, int(mean))
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        nseq, S, D, mean = ctx.dims
+        g = _f32(g, "grad")
+        dx = torch.empty(nseq, S, D, dtype=torch.float32, device=g.device)
+        check(lib().nr_seq_reduce_bwd_f32(_p(g), nseq, S, D, mean, _p(dx), _stream()), "nr_seq_reduce_bwd_f32")
+        return dx, None
+
+
+def seq_reduce(x, mean=False):
+    return _SeqReduce.apply(_f32(x, "x"), bool(mean))
+
+
+def seq_reduce_from_table(table, idx, mean=False):
+    table, idx = _f32(table, "news_embeddings"), _i64(idx, "his_idx")
+    nseq, S = idx.shape
+    D = table.shape[1]
+    out = torch.empty(nseq, D, dtype=torch.float32, device=table.device)
+    check(lib().nr_seq_reduce_f32(None, _p(table), _p(idx), table.shape[0], nseq, S, D, int(mean), _p(out), _stream()),
+          "nr_seq_reduce_f32")
+    return out
+
+
+# ----------------------------------------------------------------------------- scoring (+ cross entropy)
+class _Score(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, cdd, user):
+        B, Cn, D = cdd.shape
+        logits = torch.empty(B, Cn, dtype=torch.float32, device=cdd.device)
+        check(lib().nr_score_fwd_f32(_p(cdd), None, None, 0, _p(user), None, B, Cn, D, _p(logits), None, None, _stream()),
+              "nr_score_fwd_f32")
+        ctx.save_for_backward(cdd, user)
+        return logits
+
+    @staticmethod
+    def backward(ctx, g):
+        cdd, user = ctx.saved_tensors
+        B, Cn, D = cdd.shape
+        g = _f32(g, "grad")
+        d_cdd = torch.empty_like(cdd)
+        d_user = torch.empty_like(user)
+        check(lib().nr_score_bwd_f32(_p(cdd), _p(user), _p(g), B, Cn, D, _p(d_cdd), _p(d_user), _stream()), "nr_score_bwd_f32")
+        return d_cdd, d_user
+
+
+def score(cdd, user):
+    """_compute_logits (BaseModel.py:164-175): cdd [B,C,D], user [B,1,D] or [B,D] -> [B,C]."""
+    cdd, user = _f32(cdd, "cdd_news_repr"), _f32(user, "user_repr")
+    return _Score.apply(cdd, user.reshape(cdd.shape[0], cdd.shape[2]))
+
+
+class _ScoreCE(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, cdd, user, label):
+        B, Cn, D = cdd.shape
+        logits = torch.empty(B, Cn, dtype=torch.float32, device=cdd.device)
+        rows = torch.empty(B, dtype=torch.float32, device=cdd.device)
+        loss = torch.empty((), dtype=torch.float32, device=cdd.device)
+        check(lib().nr_score_fwd_f32(_p(cdd), None, None, 0, _p(user), _p(label), B, Cn, D, _p(logits), _p(rows), _p(loss),
+                                     _stream()), "nr_score_fwd_f32")
+        ctx.save_for_backward(cdd, user, label, logits)
+        ctx.mark_non_differentiable(logits)
+        return loss, logits
+
+    @staticmethod
+    def backward(ctx, g, _gl):
+        cdd, user, label, logits = ctx.saved_tensors
+        B, Cn, D = cdd.shape
+        g = _f32(g, "grad").reshape(1)
+        d_cdd = torch.empty_like(cdd)
+        d_user = torch.empty_like(user)
+        check(lib().nr_score_ce_bwd_f32(_p(cdd), _p(user), _p(label), _p(logits), _p(g), B, Cn, D, _p(d_cdd), _p(d_user),
+                                        _stream()), "nr_score_ce_bwd_f32")
+        return d_cdd, d_user, None
+
+
+def score_cross_entropy(cdd, user, label):
+    """fused _compute_logits + nn.CrossEntropyLoss() (BaseModel.py:202-204) -> (loss, logits)."""
+    cdd, user, label = _f32(cdd, "cdd_news_repr"), _f32(user, "user_repr"), _i64(label, "label")
+    if label.numel() and (int(label.shape[0]) != cdd.shape[0]):
+        raise NewsrecError("score_cross_entropy: label/batch mismatch")
+    return _ScoreCE.apply(cdd, user.reshape(cdd.shape[0], cdd.shape[2]), label)
+
+
+def score_from_table(table, cdd_idx, user):
+    """evaluation gather-dot: logits[r,c] = table[cdd_idx[r,c]] . user[r] / sqrt(D) (BaseModel.py:214-217)."""
+    table, cdd_idx, user = _f32(table, "news_embeddings"), _i64(cdd_idx, "cdd_idx"), _f32(user, "user_repr")
+    B, Cn = cdd_idx.shape
+    D = table.shape[1]
+    user = user.reshape(B, D)
+    logits = torch.empty(B, Cn, dtype=torch.float32, device=table.device)
+    check(lib().nr_score_fwd_f32(None, _p(table), _p(cdd_idx), table.shape[0], _p(user), None, B, Cn, D, _p(logits), None,
+                                 None, _stream()), "nr_score_fwd_f32")
+    return logits
+
+
+# ----------------------------------------------------------------------------- Adam
+def adam_step(param, grad, exp_avg, exp_avg_sq, step, lr, beta1=0.9, beta2=0.999, eps=1e-8):
+    check(lib().nr_adam_step_f32(_p(param), _p(grad), _p(exp_avg), _p(exp_avg_sq), param.numel(), lr, beta1, beta2, eps, step,
+                                 _stream()), "nr_adam_step_f32")
+
+
+# ----------------------------------------------------------------------------- profiler
+def prof_enable(on=True):
+    check(lib().nr_prof_enable(1 if on else 0), "nr_prof_enable")
+
+
+def prof_read(family):
+    ms, n, work = C.c_double(), C.c_int64(), C.c_double()
+    check(lib().nr_prof_read(family, C.byref(ms), C.byref(n), C.byref(work)), "nr_prof_read")
+    return ms.value, n.value, work.value

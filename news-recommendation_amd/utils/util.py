@@ -1,0 +1,180 @@
+"""Host-side helpers of the two-tower path: result packing, ranking metrics, samplers, Adam driver.
+
+Follows the reference's utils/util.py for everything that defines the AUC / MRR / nDCG parity
+target (pack_results :37-57, mrr/dcg/ndcg :126-194, compute_metrics :197-266, Sequential_Sampler
+:269-282, sample_news :60-76).  Rankings call the same numpy primitive on the same fp32 scores
+(np.argsort(y_score)[::-1]) so tie order is identical by construction.
+"""
+import math
+import pickle
+from random import sample
+
+import numpy as np
+import torch
+
+
+def load_pickle(path):
+    """only used on caches this package (or the user's own preprocessing) wrote"""
+    with open(path, "rb") as f:
+        return pickle.load(f)
+
+
+def save_pickle(obj, path):
+    with open(path, "wb") as f:
+        pickle.dump(obj, f)
+
+
+def pack_results(impr_indices, masks, *associated_lists):
+    """regroup per-row arrays (rows = <=impr_size-candidate chunks of an impression) by impression id,
+    first-seen order, dropping masked-out (padded) candidates.  Vectorised; returns, per associated
+    array, a list of python lists exactly like the reference."""
+    impr = np.asarray(impr_indices).reshape(-1)
+    masks = np.asarray(masks, dtype=np.bool_)
+    n = impr.shape[0]
+    if n == 0:
+        return [[] for _ in associated_lists]
+    uniq, first, inv = np.unique(impr, return_index=True, return_inverse=True)
+    group_rank = np.argsort(np.argsort(first, kind="stable"), kind="stable")[inv]     # first-seen order of each row's group
+    order = np.argsort(group_rank, kind="stable")                                   # rows grouped, original order inside
+    counts_row = masks.sum(axis=1)
+    sizes = np.bincount(group_rank, weights=counts_row, minlength=len(uniq)).astype(np.int64)
+    bounds = np.cumsum(sizes)[:-1]
+    out = []
+    for arr in associated_lists:
+        arr = np.asarray(arr)
+        flat = arr[order][masks[order]]
+        out.append([g.tolist() for g in np.split(flat, bounds)])
+    return out
+
+
+def sample_news(news, k):
+    """k negatives without replacement; zero-pad when fewer than k exist -> (list, valid_count)"""
+    num = len(news)
+    if k > num:
+        return news + [0] * (k - num), num
+    return sample(news, k), k
+
+
+def _order(y_score):
+    return np.argsort(y_score)[::-1]
+
+
+def mrr_score(y_true, y_score):
+    y = np.take(y_true, _order(y_score))
+    return np.sum(y / (np.arange(len(y)) + 1)) / np.sum(y)
+
+
+def dcg_score(y_true, y_score, k=10):
+    k = min(np.shape(y_true)[-1], k)
+    y = np.take(y_true, _order(y_score)[:k])
+    return np.sum((2 ** y - 1) / np.log2(np.arange(len(y)) + 2))
+
+
+def ndcg_score(y_true, y_score, k=10):
+    return dcg_score(y_true, y_score, k) / dcg_score(y_true, y_true, k)
+
+
+def hit_score(y_true, y_score, k=10):
+    truth = set(np.where(np.asarray(y_true) == 1)[0].tolist())
+    return int(any(int(i) in truth for i in _order(y_score)[:k]))
+
+
+def auc_score(y_true, y_score):
+    """binary ROC AUC with ties counted 1/2 (rank-sum form of what sklearn.metrics.roc_auc_score,
+    the reference's call at util.py:205, returns)."""
+    y_true = np.asarray(y_true)
+    s = np.asarray(y_score, dtype=np.float64)
+    n = s.shape[0]
+    order = np.argsort(s, kind="stable")
+    ss = s[order]
+    new = np.empty(n, dtype=bool)
+    new[0] = True
+    new[1:] = ss[1:] != ss[:-1]
+    start = np.flatnonzero(new)
+    end = np.append(start[1:], n)
+    avg = 0.5 * (start + end - 1) + 1.0                  # average 1-based rank of each tie group
+    ranks = np.empty(n, dtype=np.float64)
+    ranks[order] = np.repeat(avg, end - start)
+    pos = y_true == 1
+    n_pos = int(pos.sum())
+    n_neg = n - n_pos
+    if n_pos == 0 or n_neg == 0:
+        raise ValueError("Only one class present in y_true. ROC AUC score is not defined in that case.")
+    return (ranks[pos].sum() - n_pos * (n_pos + 1) / 2.0) / (n_pos * n_neg)
+
+
+def compute_metrics(labels, preds, metrics):
+    """mean per-impression metric, round(…, 4); keys: auc, mean_mrr, ndcg@k[;k…], hit@k[;k…]"""
+    pairs = [(np.asarray(l), np.asarray(p)) for l, p in zip(labels, preds)]
+    res = {}
+    for metric in metrics:
+        if metric == "auc":
+            res["auc"] = round(np.mean([auc_score(l, p) for l, p in pairs]), 4)
+        elif metric == "mean_mrr":
+            res["mean_mrr"] = round(np.mean([mrr_score(l, p) for l, p in pairs]), 4)
+        elif metric.startswith("ndcg") or metric.startswith("hit"):
+            fn, tag = (ndcg_score, "ndcg") if metric.startswith("ndcg") else (hit_score, "hit")
+            ks = [1, 2]
+            parts = metric.split("@")
+            if len(parts) > 1:
+                ks = [int(t) for t in parts[1].split(";")]
+            for k in ks:
+                res["{}@{}".format(tag, k)] = round(np.mean([fn(l, p, k) for l, p in pairs]), 4)
+        else:
+            raise ValueError("not define this metric {0}".format(metric))
+    return res
+
+
+class Sequential_Sampler:
+    """rank r reads the contiguous slice [round(n/ws*r), round(n/ws*(r+1)))"""
+
+    def __init__(self, dataset_length, num_replicas, rank) -> None:
+        per = dataset_length / num_replicas
+        self.start = round(per * rank)
+        self.end = round(per * (rank + 1))
+
+    def __iter__(self):
+        return iter(range(self.start, self.end))
+
+    def __len__(self):
+        return self.end - self.start
+
+
+def linear_warmup_lambda(num_warmup_steps, num_training_steps):
+    """lr multiplier of transformers.get_linear_schedule_with_warmup (reference BaseModel.py:51-53)"""
+    def fn(step):
+        if step < num_warmup_steps:
+            return float(step) / float(max(1, num_warmup_steps))
+        return max(0.0, float(num_training_steps - step) / float(max(1, num_training_steps - num_warmup_steps)))
+    return fn
+
+
+class HipAdam(torch.optim.Optimizer):
+    """torch.optim.Adam(params, lr) with its defaults (betas 0.9/0.999, eps 1e-8, no weight decay),
+    dense over every parameter incl. the V x E token table (reference BaseModel.py:46); the update
+    itself is the fused HIP kernel nr_adam_step_f32.  State keys match torch's Adam."""
+
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8):
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps))
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        from newsrec_hip import ops
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        for group in self.param_groups:
+            b1, b2 = group["betas"]
+            for p in group["params"]:
+                if p.grad is None:
+                    continue
+                st = self.state[p]
+                if not st:
+                    st["step"] = 0
+                    st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                    st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                st["step"] += 1
+                g = p.grad if p.grad.is_contiguous() else p.grad.contiguous()
+                ops.adam_step(p, g, st["exp_avg"], st["exp_avg_sq"], int(st["step"]), float(group["lr"]), b1, b2, group["eps"])
+        return loss

@@ -75,7 +75,8 @@ def _drop(x, keep_mask, p):
     """inverted dropout with an injected keep-mask (None ⇒ eval / identity)."""
     if keep_mask is None:
         return x
-    return x * keep_mask.to(x.dtype) / (1.0 - p)
+    # torch's dropout multiplies by the noise tensor bernoulli(1-p).div_(1-p)
+    return x * (keep_mask.to(x.dtype) / (1.0 - p))
 
 
 def tfm_layer(P, prefix, x, mask, head_num, drop_masks=None, p=0.1, return_all=False):

@@ -73,3 +73,47 @@ def synth_batch(g, B, C, L, Nn, ids, msk, max_hist=70):
                 cdd_token_id=ids[cdd_idx], cdd_attn_mask=msk[cdd_idx],
                 his_token_id=ids[his_idx], his_attn_mask=msk[his_idx],
                 label=torch.zeros(B, dtype=torch.int64))
+
+
+# ----------------------------------------------------------------------------- dropout stream of the HIP library
+def philox4x32_10(seed, idx, site):
+    """numpy restatement of csrc/common.h::philox4x32_10 -> uint32 array [..., 4]"""
+    idx = np.asarray(idx, dtype=np.uint64)
+    M0, M1 = np.uint64(0xD2511F53), np.uint64(0xCD9E8D57)
+    mask = np.uint64(0xFFFFFFFF)
+    k0 = np.uint64(seed & 0xFFFFFFFF)
+    k1 = np.uint64((seed >> 32) & 0xFFFFFFFF)
+    c0 = idx & mask
+    c1 = (idx >> np.uint64(32)) & mask
+    c2 = np.full_like(idx, np.uint64(site))
+    c3 = np.zeros_like(idx)
+    for _ in range(10):
+        p0 = M0 * c0
+        p1 = M1 * c2
+        hi0, lo0 = p0 >> np.uint64(32), p0 & mask
+        hi1, lo1 = p1 >> np.uint64(32), p1 & mask
+        c0, c1, c2, c3 = (hi1 ^ c1 ^ k0) & mask, lo1, (hi0 ^ c3 ^ k1) & mask, lo0
+        k0 = (k0 + np.uint64(0x9E3779B9)) & mask
+        k1 = (k1 + np.uint64(0xBB67AE85)) & mask
+    return np.stack([c0, c1, c2, c3], axis=-1).astype(np.uint32)
+
+
+def keep_mask(shape, p, seed, site):
+    """boolean keep-mask for a tensor of `shape` (element index = C-order linear index)"""
+    n = int(np.prod(shape))
+    idx = np.arange(n, dtype=np.uint64)
+    r = philox4x32_10(seed, idx >> np.uint64(2), site)
+    u = r[np.arange(n), (idx & np.uint64(3)).astype(np.int64)]
+    thr = np.uint32(min(max(float(p) * 4294967296.0, 0.0), 4294967295.0))
+    return torch.from_numpy((u >= thr).reshape(shape))
+
+
+def make_manager(**kw):
+    import types
+    base = dict(plm_dim=24, hidden_dim=24, head_num=4, his_size=5, sequence_length=8, device=0, rank=0, world_size=1,
+                negative_num=2, verbose=None, enable_fields=["title"], dropout_p=0.1, vocab_size=131, synthetic_plm=True,
+                plm_dir="/nonexistent", distributed=False, debug=False, impr_size=20, batch_size_eval=200,
+                metrics=["auc", "mean_mrr", "ndcg@5", "ndcg@10"], learning_rate=1e-3, scheduler="none", epochs=1,
+                warmup=0.1, scale="demo", checkpoint="none")
+    base.update(kw)
+    return types.SimpleNamespace(**base)
