@@ -1,0 +1,268 @@
+#!/usr/bin/env python
+"""Headline benchmark: NRMS-shape two-tower TRAINING step (news encoder = user encoder = one
+multi-head self-attention layer + additive pooling, T=32, L=50, K=4, 300-d, 12 heads) on
+synthetic MIND-large-shaped data, fp32, inputs resident in HBM.
+
+    python bench.py --gpus N --steps K --warmup W          (N>1: launched by torch.distributed.run)
+
+One "step" = forward + backward + Adam over one batch of B impressions per GPU (B = 32, the
+reference's -bs default).  Rank 0 prints ONE JSON line: train impressions/s over all ranks
+(max-over-ranks time, barrier + synchronize on both sides), plus
+  roofline     — the dominant kernel family (f32-MFMA GEMM): algorithmic flops / HIP-event time
+  cpu_baseline — the CPU oracle (oracle/, torch fp32) timed on this host's cores, N=1 only
+  eval         — cached evaluation: news-cache build (news/s) and impression scoring (rows/s)
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for _p in (ROOT, os.path.join(ROOT, "news-recommendation_amd")):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
+
+import torch
+import torch.distributed as dist
+
+V, E, D, H, T, L, K = 30522, 300, 300, 12, 32, 50, 4
+NEWS_TRAIN = 101527 + 1        # MINDlarge_train rows (+1 pad row), reference manager.py:175
+NEWS_DEV = 72023 + 1           # MINDlarge_dev
+PEAK_F32_MATRIX_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 peak
+PEAK_HBM_GBS = 8000.0
+
+
+def synth_table(g, Nn):
+    """MIND-shaped token table: row 0 all PAD; [CLS]=101 w... [SEP]=102 then PAD"""
+    lens = torch.randint(5, T + 1, (Nn,), generator=g)
+    lens[0] = 0
+    pos = torch.arange(T)[None, :]
+    msk = (pos < lens[:, None]).long()
+    ids = torch.randint(1000, V, (Nn, T), generator=g) * msk
+    ids[:, 0] = torch.where(lens > 0, torch.tensor(101), torch.tensor(0))
+    ids[torch.arange(Nn), (lens - 1).clamp(min=0)] = torch.where(lens > 0, torch.tensor(102), torch.tensor(0))
+    return ids, msk
+
+
+def synth_train_batch(g, B, Nn, ids, msk):
+    cdd_idx = torch.randint(1, Nn, (B, K + 1), generator=g)
+    nneg = torch.randint(1, 41, (B,), generator=g)                       # negatives pool 1..40, zero-padded below K
+    for b in torch.nonzero(nneg < K).flatten().tolist():
+        cdd_idx[b, 1 + int(nneg[b]):] = 0
+    hl = torch.randint(0, 71, (B,), generator=g).clamp(max=L)            # history 0..70 truncated to L
+    his_idx = torch.randint(1, Nn, (B, L), generator=g)
+    live = torch.arange(L)[None, :] < hl[:, None]
+    his_idx = his_idx * live
+    his_mask = live.long()
+    his_mask[hl == 0, 0] = 1
+    return dict(cdd_idx=cdd_idx, his_idx=his_idx, his_mask=his_mask, cdd_token_id=ids[cdd_idx], cdd_attn_mask=msk[cdd_idx],
+                his_token_id=ids[his_idx], his_attn_mask=msk[his_idx], label=torch.zeros(B, dtype=torch.int64))
+
+
+def build_model(device):
+    import types
+    from models.TwoTower import TwoTowerModel
+    from models.modules import encoder as Enc
+    mgr = types.SimpleNamespace(
+        plm_dim=E, hidden_dim=D, head_num=H, his_size=L, sequence_length=T, negative_num=K, vocab_size=V, device=device,
+        learning_rate=1e-5, rank=0, world_size=1, verbose=None, enable_fields=["title"], dropout_p=0.1, synthetic_plm=True,
+        plm_dir="", distributed=False, debug=False, impr_size=20, batch_size_eval=200, scheduler="none", epochs=1, warmup=0.1)
+    torch.manual_seed(3407)
+    model = TwoTowerModel(mgr, Enc.TfmNewsEncoder(mgr), Enc.TfmUserEncoder(mgr))
+    return model, mgr
+
+
+def train_flops_per_impression():
+    per_seq = lambda S: 26 * S * D * D + 4 * S * S * D                   # SURVEY §8d (fwd, incl. pooling projection)
+    return 3 * ((K + 1 + L) * per_seq(T) + per_seq(L))
+
+
+def cpu_baseline(B, steps=2):
+    """the oracle's train step (same shapes, same synthetic batch) on this host's cores"""
+    from oracle import twotower_oracle as O
+    cores = max(1, min(os.cpu_count() or 1, int(os.environ.get("OMP_NUM_THREADS", "0")) or (os.cpu_count() or 1)))
+    torch.set_num_threads(cores)
+    model, _ = build_model("cpu")
+    P = {k: v.detach().clone().requires_grad_(True) for k, v in model.state_dict().items()}
+    g = torch.Generator().manual_seed(0)
+    ids, msk = synth_table(g, 20000)
+    X = synth_train_batch(g, B, 20000, ids, msk)
+    params = list(P.values())
+    opt = torch.optim.Adam(params, lr=1e-5)
+    times = []
+    for i in range(steps + 1):
+        t0 = time.perf_counter()
+        opt.zero_grad(set_to_none=True)
+        loss, _ = O.train_forward(P, "tfm", "tfm", X, head_num=H)
+        loss.backward()
+        opt.step()
+        times.append(time.perf_counter() - t0)
+    best = min(times[1:])
+    return {"value": round(B / best, 3), "unit": "train impressions/s", "cores": cores, "kind": "port",
+            "sample": f"{steps} timed oracle (torch-fp32 CPU restatement) train steps of B={B} after 1 warm-up, min taken; "
+                      "eval-mode dropout"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch-size", type=int, default=32, help="impressions per GPU per step (reference -bs default)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-eval", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the product has no CPU path")
+    torch.cuda.set_device(local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+    from newsrec_hip import ops
+
+    B = args.batch_size
+    model, mgr = build_model(local)
+    model = model.cuda().train()
+    net = model
+    if world > 1:
+        net = torch.nn.parallel.DistributedDataParallel(model, device_ids=[local], output_device=local,
+                                                        gradient_as_bucket_view=True)
+    opt, _ = model.get_optimizer(mgr, 1000)
+
+    g = torch.Generator().manual_seed(1000 + rank)
+    ids, msk = synth_table(g, NEWS_TRAIN)
+    batches = []
+    for _ in range(8):                                                    # pre-staged in HBM: the path, not the loader
+        X = synth_train_batch(g, B, NEWS_TRAIN, ids, msk)
+        batches.append({k: v.cuda() for k, v in X.items()})
+
+    def step(i):
+        opt.zero_grad(set_to_none=True)
+        loss = net(batches[i % len(batches)])
+        loss.backward()
+        opt.step()
+        return loss
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        step(i)
+    fence()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        loss = step(i)
+    fence()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], device="cuda", dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    final_loss = float(loss)
+    ms_per_step = 1000.0 * dt / args.steps
+    value = world * B * args.steps / dt
+
+    # ---- roofline leg: same steps with HIP events around every launch of each kernel family
+    ops.prof_enable(True)
+    for i in range(args.steps):
+        step(i)
+    torch.cuda.synchronize()
+    fam = {}
+    for name, idx in (("gemm", 0), ("gather", 1), ("attention", 2), ("layernorm", 3), ("pool", 4), ("score", 5), ("misc", 6)):
+        ms, n, work = ops.prof_read(idx)
+        fam[name] = dict(ms_per_step=round(ms / args.steps, 4), launches_per_step=n / args.steps, work_per_step=work / args.steps)
+    ops.prof_enable(False)
+    gm = fam["gemm"]
+    gemm_tflops = gm["work_per_step"] / (gm["ms_per_step"] * 1e-3) / 1e12 if gm["ms_per_step"] > 0 else 0.0
+    roofline = {"kernel": "gemm_f32_kernel (v_mfma_f32_32x32x2_f32), all GEMM launches of one train step",
+                "bound": "mfma", "achieved": round(gemm_tflops, 2), "peak": PEAK_F32_MATRIX_TFLOPS, "unit": "TFLOP/s",
+                "frac": round(gemm_tflops / PEAK_F32_MATRIX_TFLOPS, 4), "traffic": None,
+                "launches_per_step": gm["launches_per_step"], "avg_launch_ms": round(gm["ms_per_step"] / max(gm["launches_per_step"], 1), 5),
+                "flops_per_step": gm["work_per_step"]}
+    hbm = {}
+    for name in ("gather", "layernorm", "pool", "score"):
+        f = fam[name]
+        if f["ms_per_step"] > 0:
+            gbs = f["work_per_step"] / (f["ms_per_step"] * 1e-3) / 1e9
+            hbm[name] = {"GB/s": round(gbs, 1), "frac_of_8TBs": round(gbs / PEAK_HBM_GBS, 4), "ms_per_step": f["ms_per_step"]}
+
+    out = {
+        "metric": "train impressions/sec (node), NRMS-shape MIND-large; eval impressions/sec",
+        "value": round(value, 2), "unit": "impressions/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "configs[1]: NRMS-style MHSA news+user encoder (TwoTower-Tfm-Tfm), T=32, L=50, K=4, 300-d, "
+                               "12 heads, train step = fwd+bwd+Adam with dropout 0.1",
+                   "per_gpu_batch": B, "global_batch": B * world, "vocab": V, "parallelism": f"dp{world}"},
+        "loss": round(final_loss, 5),
+        "model_tflops": round(value * train_flops_per_impression() / 1e12, 2),
+        "roofline": roofline, "hbm_kernels": hbm, "kernel_ms_per_step": {k: v["ms_per_step"] for k, v in fam.items()},
+    }
+
+    # ---- cached evaluation leg (BASELINE config 4 shape, per GPU): cache build + impression scoring
+    if not args.no_eval:
+        model.eval()
+        gd = torch.Generator().manual_seed(7)
+        dids, dmsk = synth_table(gd, NEWS_DEV)
+        dids, dmsk = dids.cuda(), dmsk.cuda()
+        lo, hi = round(NEWS_DEV / world * rank), round(NEWS_DEV / world * (rank + 1))
+        with torch.no_grad():
+            def encode():
+                outs = []
+                for s in range(lo, hi, 8192):
+                    outs.append(model.newsEncoder(dids[s:min(hi, s + 8192)], dmsk[s:min(hi, s + 8192)])[1])
+                return torch.cat(outs)
+            encode()
+            fence()
+            t0 = time.perf_counter()
+            part = encode()
+            fence()
+            t_enc = time.perf_counter() - t0
+            cache = torch.zeros(NEWS_DEV, D, device="cuda")
+            cache[lo:hi] = part
+            if world > 1:
+                dist.all_reduce(cache)
+            model.news_embeddings = cache
+            Re, Ce = 200, 20
+            rows = []
+            for _ in range(8):
+                x = {"cdd_idx": torch.randint(0, NEWS_DEV, (Re, Ce), generator=gd).cuda(),
+                     "his_idx": torch.randint(0, NEWS_DEV, (Re, L), generator=gd).cuda(),
+                     "his_mask": torch.ones(Re, L, dtype=torch.int64).cuda()}
+                rows.append(x)
+            for i in range(3):
+                model.infer(rows[i])
+            fence()
+            n_it = 50
+            t0 = time.perf_counter()
+            for i in range(n_it):
+                model.infer(rows[i % 8])
+            fence()
+            t_inf = time.perf_counter() - t0
+        if world > 1:
+            tt = torch.tensor([t_enc, t_inf], device="cuda", dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            t_enc, t_inf = [float(v) for v in tt.tolist()]
+        out["eval"] = {"news_cache_rows": NEWS_DEV, "cache_build_news_per_s": round(NEWS_DEV / t_enc, 1),
+                       "infer_rows_per_s": round(world * n_it * Re / t_inf, 1),
+                       "note": "eval rows = <=20-candidate chunks of an impression (batch 200, Ce=20, L=50), tfm user encoder"}
+
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(B)
+    elif rank == 0:
+        out["cpu_baseline"] = None
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

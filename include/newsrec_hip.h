@@ -159,8 +159,9 @@ size_t nr_tfm_layer_bwd_ws_bytes(int64_t N, int64_t S, int64_t D);
 int nr_tfm_layer_bwd_f32(const float* dy, const float* x, const int64_t* mask, int64_t N, int64_t S, int64_t D, int64_t H, const nr_tfm_weights* w, float p_drop, uint64_t seed, uint32_t site_base, const nr_tfm_saved* saved, nr_tfm_grads* grads, float* dx, void* ws, size_t ws_bytes, void* stream);
 
 /* ---- dense Adam — optim.Adam(lr) in BaseModel.get_optimizer, models/BaseModel.py:45-46 ----------
- * torch defaults (betas 0.9/0.999, eps 1e-8, no weight decay, no amsgrad); step counts from 1. */
-int nr_adam_step_f32(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr, float beta1, float beta2, float eps, int64_t step, void* stream);
+ * torch defaults (betas 0.9/0.999, eps 1e-8, no weight decay, no amsgrad); step counts from 1.
+ * Hyper-parameters are doubles: torch forms 1-beta, lr/(1-beta1^t), sqrt(1-beta2^t) in double before rounding to fp32. */
+int nr_adam_step_f32(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, double lr, double beta1, double beta2, double eps, int64_t step, void* stream);
 
 #ifdef __cplusplus
 }

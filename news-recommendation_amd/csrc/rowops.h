@@ -27,7 +27,7 @@ int conv_unpack_grad(const float* gwf, float* gw, int D, int E, hipStream_t s);
 int add_f32(const float* a, const float* b, float* o, int64_t n, hipStream_t s);
 int relu_bwd_f32(const float* dy, const float* y, float* o, int64_t n, hipStream_t s);
 int mean_f32(const float* v, int n, float* out, hipStream_t s);
-int adam_f32(float* p, const float* g, float* m, float* v, int64_t n, float lr, float b1, float b2, float eps, int64_t step,
+int adam_f32(float* p, const float* g, float* m, float* v, int64_t n, double lr, double b1, double b2, double eps, int64_t step,
              hipStream_t s);
 
 }  // namespace nr

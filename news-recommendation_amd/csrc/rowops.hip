@@ -431,27 +431,29 @@ int mean_f32(const float* v, int n, float* out, hipStream_t s) {
 
 // ------------------------------------------------------------------ Adam (torch.optim.Adam defaults, dense)
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
-                                                   float* __restrict__ v, int64_t n, float b1, float b2, float eps,
-                                                   float step_size, float bc2_sqrt) {
+                                                   float* __restrict__ v, int64_t n, float omb1, float b2, float omb2,
+                                                   float eps, float step_size, float bc2_sqrt) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
         const float gi = g[i];
-        const float mi = m[i] + (1.0f - b1) * (gi - m[i]);            // exp_avg.lerp_(grad, 1-beta1)
-        const float vi = v[i] * b2 + (1.0f - b2) * gi * gi;           // mul_(beta2).addcmul_(g, g, 1-beta2)
+        const float mi = m[i] + omb1 * (gi - m[i]);                   // exp_avg.lerp_(grad, 1-beta1)
+        const float vi = v[i] * b2 + omb2 * gi * gi;                  // mul_(beta2).addcmul_(g, g, 1-beta2)
         const float denom = sqrtf(vi) / bc2_sqrt + eps;
         p[i] = p[i] - step_size * (mi / denom);                      // addcdiv_(exp_avg, denom, -step_size)
         m[i] = mi; v[i] = vi;
     }
 }
-int adam_f32(float* p, const float* g, float* m, float* v, int64_t n, float lr, float b1, float b2, float eps, int64_t step,
+int adam_f32(float* p, const float* g, float* m, float* v, int64_t n, double lr, double b1, double b2, double eps, int64_t step,
              hipStream_t s) {
     if (n == 0) return NR_OK;
-    const double bc1 = 1.0 - pow((double)b1, (double)step);
-    const double bc2 = 1.0 - pow((double)b2, (double)step);
-    const float step_size = (float)((double)lr / bc1);
+    const double bc1 = 1.0 - pow(b1, (double)step);
+    const double bc2 = 1.0 - pow(b2, (double)step);
+    const float step_size = (float)(lr / bc1);
     const float bc2_sqrt = (float)sqrt(bc2);
+    // torch forms 1-beta in python doubles and only then rounds to fp32 (1.0f - 0.999f is 4.7e-5 off)
+    const float omb1 = (float)(1.0 - b1), omb2 = (float)(1.0 - b2);
     ProfScope prof(FAM_MISC, s, (double)n * 4 * 7);
-    hipLaunchKernelGGL(adam_kernel, dim3((int)std::min<int64_t>(cdiv(n, 256), 8192)), dim3(256), 0, s, p, g, m, v, n, b1, b2,
-                       eps, step_size, bc2_sqrt);
+    hipLaunchKernelGGL(adam_kernel, dim3((int)std::min<int64_t>(cdiv(n, 256), 8192)), dim3(256), 0, s, p, g, m, v, n, omb1, (float)b2,
+                       omb2, (float)eps, step_size, bc2_sqrt);
     return check_launch("adam");
 }
 

@@ -120,15 +120,19 @@ def test_conv1d_k3_relu(ops, M, T, E, D):
     g = G(6)
     x = torch.randn(M, T, E, generator=g)
     conv = torch.nn.Conv1d(E, D, 3, padding=1)
-    xr = x.clone().requires_grad_(True)
-    yr = F.relu(conv(xr.transpose(1, 2))).transpose(1, 2)
     wgt = torch.randn(M, T, D, generator=g)
-    (yr * wgt).sum().backward()
     xg = x.cuda().requires_grad_(True)
     wg = conv.weight.detach().cuda().requires_grad_(True)
     bg = conv.bias.detach().cuda().requires_grad_(True)
     yg = ops.conv1d_k3_relu(xg, wg, bg)
     (yg * wgt.cuda()).sum().backward()
+    xr = x.clone().requires_grad_(True)
+    zr = conv(xr.transpose(1, 2)).transpose(1, 2)
+    yr = F.relu(zr)
+    # pre-activations within rounding of 0 may land on either side of the ReLU: take the gate the
+    # kernel took for those (|z| < 1e-5), the reference's own everywhere else
+    gate = torch.where(zr.detach().abs() < 1e-5, yg.detach().cpu() > 0, zr.detach() > 0).float()
+    (zr * gate * wgt).sum().backward()
     assert relerr(yg, yr) < FP32_TOL
     assert relerr(xg.grad, xr.grad) < FP32_TOL
     assert relerr(wg.grad, conv.weight.grad) < 2e-5        # reduction over M*T rows
@@ -156,11 +160,11 @@ def test_add_layernorm(ops, R, D, p):
     y_ref = F.layer_norm(s_ref, (D,), gr, br, eps=1e-12)
     y_ref.backward(dy)
     L = ops.lib()
-    hg, xg = h.cuda(), x.cuda()
+    hg, xg, gam, bet, dyg = h.cuda(), x.cuda(), gamma.cuda(), beta.cuda(), dy.cuda()      # keep alive: raw pointers below
     y = torch.empty(R, D, device="cuda"); s = torch.empty(R, D, device="cuda")
     mean = torch.empty(R, device="cuda"); rstd = torch.empty(R, device="cuda")
     st = torch.cuda.current_stream().cuda_stream
-    ops.check(L.nr_add_layernorm_fwd_f32(hg.data_ptr(), xg.data_ptr(), gamma.cuda().data_ptr(), beta.cuda().data_ptr(), R, D,
+    ops.check(L.nr_add_layernorm_fwd_f32(hg.data_ptr(), xg.data_ptr(), gam.data_ptr(), bet.data_ptr(), R, D,
                                          1e-12, p, seed, site, y.data_ptr(), s.data_ptr(), mean.data_ptr(), rstd.data_ptr(), st))
     assert relerr(y, y_ref) < FP32_TOL
     assert relerr(s, s_ref) < FP32_TOL
@@ -168,8 +172,7 @@ def test_add_layernorm(ops, R, D, p):
     dg = torch.empty(D, device="cuda"); db = torch.empty(D, device="cuda")
     nb = L.nr_layernorm_bwd_ws_bytes(R, D)
     ws = torch.empty(nb // 4 + 4, device="cuda")
-    gam = gamma.cuda()
-    ops.check(L.nr_add_layernorm_bwd_f32(dy.cuda().data_ptr(), s.data_ptr(), mean.data_ptr(), rstd.data_ptr(), gam.data_ptr(),
+    ops.check(L.nr_add_layernorm_bwd_f32(dyg.data_ptr(), s.data_ptr(), mean.data_ptr(), rstd.data_ptr(), gam.data_ptr(),
                                          R, D, p, seed, site, ds.data_ptr(), dh.data_ptr(), dg.data_ptr(), db.data_ptr(),
                                          ws.data_ptr(), ws.numel() * 4, st))
     assert relerr(ds, xr.grad) < 2e-5
@@ -229,16 +232,17 @@ def test_mhsa(ops, N, S, H, dh, p):
 def test_mhsa_masked_quantisation_exact(ops):
     """integer-valued inputs make every dot product exact, so the kernel must reproduce the
     reference's fl32(score/sqrt(dh) - 1e5) quantisation on a fully masked row BIT FOR BIT-ish."""
-    N, S, H, dh = 1, 8, 1, 4
+    N, S, H, dh = 1, 8, 1, 5
     g = G(9)
     qkv = torch.randint(-3, 4, (N * S, 3 * dh), generator=g).float()
     mask = torch.zeros(N, S, dtype=torch.int64)
     ref = _mhsa_ref(qkv, mask, N, S, H, dh, None, 0.0)
-    unq = torch.softmax(torch.matmul(qkv[:, :dh], qkv[:, dh:2 * dh].t()) / 2.0, -1) @ qkv[:, 2 * dh:]
+    unq = torch.softmax(torch.matmul(qkv[:, :dh], qkv[:, dh:2 * dh].t()) / math.sqrt(dh), -1) @ qkv[:, 2 * dh:]
     assert (ref - unq).abs().max() > 1e-3, "test vector must exercise the quantisation"
     L = ops.lib()
     ctx = torch.empty(N * S, dh, device="cuda")
-    ops.check(L.nr_mhsa_fwd_f32(qkv.cuda().data_ptr(), mask.cuda().data_ptr(), N, S, H, dh, 0.0, 0, 0, ctx.data_ptr(), None, None,
+    qg, mg = qkv.cuda(), mask.cuda()
+    ops.check(L.nr_mhsa_fwd_f32(qg.data_ptr(), mg.data_ptr(), N, S, H, dh, 0.0, 0, 0, ctx.data_ptr(), None, None,
                                 torch.cuda.current_stream().cuda_stream))
     assert relerr(ctx, ref) < 1e-6
 
