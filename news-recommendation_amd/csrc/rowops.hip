@@ -327,35 +327,80 @@ int ln_bwd(const float* dy, const float* sin, const float* mean, const float* rs
 }
 
 // ------------------------------------------------------------------ column sums
-// out[n] (+)= sum_r in[r, n]; two deterministic stages through `part` [nchunk, N].
+// out[n] = sum_r in[r, n]; two deterministic stages through `part` [nchunk, N].
+// Block = 16 column-quads (64 columns, 256 contiguous bytes per row) x 16 row lanes; grid =
+// (column tiles, row chunks).  Each lane keeps 4 independent float4 accumulators in flight.
+template <int VEC>
 __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ in, int64_t ld, float* __restrict__ out,
                                                      int64_t R, int N, int64_t rows_per_block) {
-    const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
+    __shared__ float red[16][64 + 1];
+    const int cx = threadIdx.x & 15, ry = threadIdx.x >> 4;
+    const int c0 = blockIdx.x * 64 + cx * 4;
+    const int64_t r0 = (int64_t)blockIdx.y * rows_per_block;
     const int64_t r1 = min(R, r0 + rows_per_block);
-    for (int c = threadIdx.x; c < N; c += 256) {
-        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-        int64_t r = r0;
-        for (; r + 3 < r1; r += 4) {
-            a0 += in[r * ld + c]; a1 += in[(r + 1) * ld + c]; a2 += in[(r + 2) * ld + c]; a3 += in[(r + 3) * ld + c];
+    float4 a[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) a[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (c0 < N) {
+        int64_t r = r0 + ry;
+        if (VEC == 4) {
+            for (; r + 48 < r1; r += 64) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const float4 v = *reinterpret_cast<const float4*>(in + (r + 16 * u) * ld + c0);
+                    a[u].x += v.x; a[u].y += v.y; a[u].z += v.z; a[u].w += v.w;
+                }
+            }
+            for (; r < r1; r += 16) {
+                const float4 v = *reinterpret_cast<const float4*>(in + r * ld + c0);
+                a[0].x += v.x; a[0].y += v.y; a[0].z += v.z; a[0].w += v.w;
+            }
+        } else {
+            for (; r < r1; r += 16) {
+                const float* q = in + r * ld + c0;
+                a[0].x += q[0];
+                if (c0 + 1 < N) a[0].y += q[1];
+                if (c0 + 2 < N) a[0].z += q[2];
+                if (c0 + 3 < N) a[0].w += q[3];
+            }
         }
-        for (; r < r1; ++r) a0 += in[r * ld + c];
-        out[(int64_t)blockIdx.x * N + c] = (a0 + a1) + (a2 + a3);
+    }
+    red[ry][cx * 4 + 0] = (a[0].x + a[1].x) + (a[2].x + a[3].x);
+    red[ry][cx * 4 + 1] = (a[0].y + a[1].y) + (a[2].y + a[3].y);
+    red[ry][cx * 4 + 2] = (a[0].z + a[1].z) + (a[2].z + a[3].z);
+    red[ry][cx * 4 + 3] = (a[0].w + a[1].w) + (a[2].w + a[3].w);
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        const int c = blockIdx.x * 64 + threadIdx.x;
+        if (c < N) {
+            float t = 0.f;
+#pragma unroll
+            for (int k = 0; k < 16; ++k) t += red[k][threadIdx.x];
+            out[(int64_t)blockIdx.y * N + c] = t;
+        }
     }
 }
 
-int colsum_chunks(int64_t R) { return (int)std::max<int64_t>(1, std::min<int64_t>(cdiv(R, 64), 1024)); }
+int colsum_chunks(int64_t R) { return (int)std::max<int64_t>(1, std::min<int64_t>(cdiv(R, 128), 512)); }
 
 int colsum(const float* in, int64_t ld, int64_t R, int N, float* out, float* part, hipStream_t s) {
     if (N == 0) return NR_OK;
     ProfScope prof(FAM_MISC, s, (double)R * N * 4);
-    const int nchunk = colsum_chunks(R);
-    if (nchunk == 1 || !part) {
-        hipLaunchKernelGGL(colsum_kernel, dim3(1), dim3(256), 0, s, in, ld, out, R, N, std::max<int64_t>(R, 1));
+    const int ctiles = cdiv(N, 64);
+    const bool vec = (N % 4 == 0) && (ld % 4 == 0) && aligned16(in);
+    const int nchunk = part ? colsum_chunks(R) : 1;
+#define NR_COLSUM(V, GRID, IN, LD, OUT, ROWS, RPB) hipLaunchKernelGGL(colsum_kernel<V>, GRID, dim3(256), 0, s, IN, LD, OUT, ROWS, N, RPB)
+    if (nchunk == 1) {
+        if (vec) NR_COLSUM(4, dim3(ctiles, 1), in, ld, out, R, std::max<int64_t>(R, 1));
+        else     NR_COLSUM(1, dim3(ctiles, 1), in, ld, out, R, std::max<int64_t>(R, 1));
         return check_launch("colsum");
     }
     const int64_t rpb = cdiv(R, nchunk);
-    hipLaunchKernelGGL(colsum_kernel, dim3(nchunk), dim3(256), 0, s, in, ld, part, R, N, rpb);
-    hipLaunchKernelGGL(colsum_kernel, dim3(1), dim3(256), 0, s, part, (int64_t)N, out, (int64_t)nchunk, N, (int64_t)nchunk);
+    if (vec) NR_COLSUM(4, dim3(ctiles, nchunk), in, ld, part, R, rpb);
+    else     NR_COLSUM(1, dim3(ctiles, nchunk), in, ld, part, R, rpb);
+    if (N % 4 == 0) NR_COLSUM(4, dim3(ctiles, 1), part, (int64_t)N, out, (int64_t)nchunk, (int64_t)nchunk);
+    else            NR_COLSUM(1, dim3(ctiles, 1), part, (int64_t)N, out, (int64_t)nchunk, (int64_t)nchunk);
+#undef NR_COLSUM
     return check_launch("colsum");
 }
 

@@ -143,8 +143,17 @@ class TwoTowerBaseModel(BaseModel):
         return self.userEncoder(his_news_embedding, his_mask=his_mask)
 
     def forward(self, x):
-        _, cdd_news_embedding = self._encode_news(x)
-        user_embedding = self._encode_user(x)
+        """mean softmax-CE of the clicked candidate (label 0) among 1+K candidates (reference
+        BaseModel.py:198-205).  Titles are encoded independently of each other, so the candidate and
+        history titles of the batch go through the news encoder as ONE [B, C+L, T] call (the reference
+        makes two calls; per-title results are identical) and are split afterwards."""
+        cdd_ids = x["cdd_token_id"].to(self.device)
+        C = cdd_ids.shape[1]
+        ids = torch.cat([cdd_ids, x["his_token_id"].to(self.device)], dim=1)
+        masks = torch.cat([x["cdd_attn_mask"].to(self.device), x["his_attn_mask"].to(self.device)], dim=1)
+        _, news = self.newsEncoder(ids, masks)
+        cdd_news_embedding = news[:, :C]
+        user_embedding = self.userEncoder(news[:, C:], his_mask=x["his_mask"].to(self.device))
         labels = x["label"].to(self.device)
         loss, _ = ops.score_cross_entropy(cdd_news_embedding, user_embedding, labels)
         return loss
