@@ -1,0 +1,46 @@
+"""python -m main.twotower [flags] — train / evaluate a two-tower recommender on MI355X.
+
+Same entry, flags and encoder selection as the reference's main/twotower.py:8-63: one process per
+GPU (mp.spawn), DistributedDataParallel over the "nccl" backend (RCCL over xGMI on ROCm).
+"""
+import torch.multiprocessing as mp
+from torch.nn.parallel import DistributedDataParallel as DDP
+
+from utils.manager import Manager
+from models.TwoTower import TwoTowerModel
+from models.modules import encoder as E
+
+NEWS_ENCODERS = {"cnn": E.CnnNewsEncoder, "bert": E.AllBertNewsEncoder, "tfm": E.TfmNewsEncoder}
+USER_ENCODERS = {"rnn": E.RnnUserEncoder, "sum": E.SumUserEncoder, "avg": E.AvgUserEncoder, "attn": E.AttnUserEncoder,
+                 "tfm": E.TfmUserEncoder}
+
+
+def main(rank, manager):
+    manager.setup(rank)
+    loaders = manager.prepare()
+    if manager.newsEncoder not in NEWS_ENCODERS or manager.userEncoder not in USER_ENCODERS:
+        raise ValueError(f"unknown encoder pair -ne {manager.newsEncoder} -ue {manager.userEncoder}")
+    model = TwoTowerModel(manager, NEWS_ENCODERS[manager.newsEncoder](manager), USER_ENCODERS[manager.userEncoder](manager))
+    model = model.to(manager.device)
+    if manager.mode == "train":
+        if manager.world_size > 1:
+            # gradient buckets are views of the flat all-reduce buffers: the dense V x E table gradient
+            # (the bulk of the bytes) is reduced in place, overlapped with the rest of the backward
+            kw = dict(device_ids=[manager.device], output_device=manager.device) if manager.device != "cpu" else {}
+            model = DDP(model, gradient_as_bucket_view=True, **kw)
+        return manager.train(model, loaders)
+    if manager.mode == "dev":
+        manager.load(model)
+        return model.dev(manager, loaders, log=True)
+    if manager.mode == "test":
+        manager.load(model)
+        return model.test(manager, loaders)
+    raise ValueError(f"unknown mode {manager.mode}")
+
+
+if __name__ == "__main__":
+    manager = Manager({"enable_fields": ["title"], "newsEncoder": "cnn", "userEncoder": "rnn"})
+    if manager.world_size > 1:
+        mp.spawn(main, args=(manager,), nprocs=manager.world_size, join=True)
+    else:
+        main(manager.device, manager)

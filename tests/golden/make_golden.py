@@ -241,9 +241,41 @@ def dump_metrics():
     print("metrics", res)
 
 
+def dump_dataset(tmp):
+    """the reference's MIND_Train / MIND_Dev / MIND_News items on a small synthetic cache (written by
+    news-recommendation_amd/utils/synthetic.py in the reference's pickle formats)."""
+    import importlib.util
+    import random
+    from utils import dataset as R_ds
+    spec = importlib.util.spec_from_file_location("nr_synth", os.path.join(os.path.dirname(OUT), "..", "news-recommendation_amd", "utils", "synthetic.py"))
+    synth = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(synth)
+    mgr = types.SimpleNamespace(
+        his_size=12, impr_size=6, max_title_length=24, max_abs_length=48, title_length=16, abs_length=32, negative_num=4,
+        cache_root=os.path.join(tmp, "cache"), data_root=os.path.join(tmp, "data"), rank=0, distributed=False,
+        news_nums={"MINDdemo_train": 300, "MINDdemo_dev": 200}, scale="demo", mode="train", vocab_size=5000,
+        special_token_ids={"[PAD]": 0, "[CLS]": 101, "[SEP]": 102, "punctuations": {}}, sequence_length=16,
+        enable_fields=["title"])
+    synth.write_synthetic_caches(mgr, n_train_impr=40, n_dev_impr=15, seed=11)
+    blob = {}
+    tr, dv, nw = R_ds.MIND_Train(mgr), R_ds.MIND_Dev(mgr), R_ds.MIND_News(mgr)
+    blob["train.len"], blob["dev.len"], blob["news.len"] = np.asarray(len(tr)), np.asarray(len(dv)), np.asarray(len(nw))
+    blob["train.token_ids"], blob["train.attn_masks"] = tr.token_ids, tr.attn_masks
+    blob["news.token_ids"], blob["news.attn_masks"] = nw.token_ids, nw.attn_masks
+    random.seed(5)
+    for name, ds in (("train", tr), ("dev", dv)):
+        items = [ds[i] for i in range(len(ds))]
+        for k in items[0]:
+            blob[f"{name}.{k}"] = np.stack([np.asarray(it[k]) for it in items])
+    blob["news.item7.cdd_token_id"] = nw[7]["cdd_token_id"]
+    np.savez_compressed(os.path.join(OUT, "dataset.npz"), **blob)
+    print("dataset ok", len(tr), len(dv), len(nw))
+
+
 def main():
     tmp = tempfile.mkdtemp(prefix="golden_plm_")
     try:
+        dump_dataset(tmp)
         dump_primitives()
         dump_metrics()
         seed = 100

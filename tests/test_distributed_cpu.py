@@ -1,0 +1,103 @@
+"""world_size-2 tests of the N>1 path on CPU (gloo): sharded news-cache build + all-gather, sharded
+impression scoring + typed gather + metrics.  The HIP kernels cannot run here, so the two compute
+hooks (`_encode_news`, `infer`) are replaced by the CPU oracle: what is under test is the product's
+sharding / collective / regrouping logic, which is device independent."""
+import os
+import socket
+import sys
+import tempfile
+import types
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+import helpers
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _build(tmp, world, rank):
+    from utils.manager import Manager
+    from utils.synthetic import write_synthetic_caches
+    from models.TwoTower import TwoTowerModel
+    from models.modules import encoder as E
+    from oracle import twotower_oracle as O
+    m = Manager({"enable_fields": ["title"]}, command=f"-d cpu -s demo -m dev -ne cnn -ue attn -hd 20 -tl 16 -hs 12 -is 6 -bse 7 -ws {world} "
+                                                      f"--synthetic-plm -cr {tmp}/cache -dr {tmp}/data".split())
+    m.vocab_size, m.plm_dim = 5000, 24
+    m.news_nums = {"MINDdemo_train": 300, "MINDdemo_dev": 200}
+    if rank == 0:
+        write_synthetic_caches(m, n_train_impr=8, n_dev_impr=33, seed=3, splits=("dev",))
+    return m, TwoTowerModel, E, O
+
+
+def _hook_oracle(model, O):
+    P = {k: v.detach() for k, v in model.state_dict().items()}
+
+    def enc(x, cdd=True):
+        key = "cdd" if cdd else "his"
+        return O.cnn_news_encoder(P, x[key + "_token_id"], x[key + "_attn_mask"])
+
+    def infer(x):
+        return O.infer(P, "attn", model.news_embeddings, x["cdd_idx"], x["his_idx"], x["his_mask"])
+    model._encode_news = enc
+    model.infer = infer
+
+
+def _worker(rank, world, tmp, port, q):
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    for p in (helpers.__file__,):
+        pass
+    m, TwoTowerModel, E, O = _build(tmp, world, rank)
+    m.setup(rank)
+    m.barrier()
+    torch.manual_seed(3407)
+    model = TwoTowerModel(m, E.CnnNewsEncoder(m), E.AttnUserEncoder(m))
+    _hook_oracle(model, O)
+    loaders = m.prepare()
+    metrics = model.dev(m, loaders)
+    cache = model.news_embeddings.clone()
+    shard = (loaders["dev"].sampler.start, loaders["dev"].sampler.end)
+    q.put((rank, metrics, cache.numpy(), shard))
+    m.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_sharded_eval_world2_equals_single_process():
+    tmp = tempfile.mkdtemp(prefix="nr_dist_")
+    # single process reference run
+    m, TwoTowerModel, E, O = _build(tmp, 1, 0)
+    m.setup(0)
+    torch.manual_seed(3407)
+    model = TwoTowerModel(m, E.CnnNewsEncoder(m), E.AttnUserEncoder(m))
+    _hook_oracle(model, O)
+    loaders = m.prepare()
+    single = model.dev(m, loaders)
+    cache1 = model.news_embeddings.numpy()
+    assert cache1.shape == (201, 20) and set(single) >= {"auc", "mean_mrr", "ndcg@5", "ndcg@10", "main"}
+
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, tmp, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = sorted([q.get(timeout=240) for _ in range(2)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (_, met0, c0, s0), (_, met1, c1, s1) = got
+    assert met1 is None and met0 == single                      # rank 0 reports, identical to 1 process
+    assert np.array_equal(c0, cache1) and np.array_equal(c1, cache1)   # every rank holds the whole cache
+    n = len(loaders["dev"].dataset)
+    assert s0 == (0, round(n / 2)) and s1 == (round(n / 2), n)  # contiguous impression shards
