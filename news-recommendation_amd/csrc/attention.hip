@@ -222,6 +222,10 @@ static int pick_dhp(int dh) { return dh <= 32 ? 32 : (dh <= 64 ? 64 : (dh <= 128
 int mhsa_fwd(const float* qkv, const int64_t* mask, float* ctx, float* row_max, float* row_sum, int64_t N, int S, int H,
              int dh, DropoutCfg dc, hipStream_t s) {
     if (N == 0) return NR_OK;
+    if (mhsa_mfma_supported(S, dh)) {
+        ProfScope prof(FAM_ATTN, s, 4.0 * N * H * S * S * dh);
+        return mhsa_fwd_mfma(qkv, mask, ctx, row_max, row_sum, N, S, H, dh, dc, s);
+    }
     NR_UNSUPPORTED(S > 64 || S < 1, "mhsa: sequence length %d not in [1,64]", S);
     const int dhp = pick_dhp(dh);
     NR_UNSUPPORTED(dhp == 0, "mhsa: head dim %d > 128", dh);
@@ -242,6 +246,10 @@ int mhsa_fwd(const float* qkv, const int64_t* mask, float* ctx, float* row_max, 
 int mhsa_bwd(const float* qkv, const int64_t* mask, const float* ctx, const float* dctx, const float* row_max,
              const float* row_sum, float* dqkv, int64_t N, int S, int H, int dh, DropoutCfg dc, hipStream_t s) {
     if (N == 0) return NR_OK;
+    if (mhsa_mfma_supported(S, dh)) {
+        ProfScope prof(FAM_ATTN, s, 10.0 * N * H * S * S * dh);
+        return mhsa_bwd_mfma(qkv, mask, dctx, row_max, row_sum, dqkv, N, S, H, dh, dc, s);
+    }
     NR_UNSUPPORTED(S > 64 || S < 1, "mhsa bwd: sequence length %d not in [1,64]", S);
     const int dhp = pick_dhp(dh);
     NR_UNSUPPORTED(dhp == 0 || dhp > 64, "mhsa bwd: head dim %d > 64", dh);

@@ -39,23 +39,45 @@ __device__ __forceinline__ bool conv_masked(int r, int c, int T, int E) {
 }
 
 // ---- global -> register staging -------------------------------------------------
+// Per-thread loader state is computed ONCE per tile (row pointers, validity, conv border flags);
+// per k-tile only `k < K` and the pointer bump remain.
+//
 // k-contiguous operand: tile ROWS x 32 floats, thread loads float4 (row = t/8 + 32*i, k = (t%8)*4)
 template <int ROWS>
-__device__ __forceinline__ void load_kc(float4 (&reg)[ROWS / 32], const float* __restrict__ base, int64_t ld,
-                                        int row0, int nrows, int k0, int K, int tid, int convT, int convE) {
-    const int c4 = (tid & 7) * 4;
-    const int r0 = tid >> 3;
+struct LoaderKC {
+    const float* ptr[ROWS / 32];   // &base[row*ld + c4]
+    unsigned flags;                // per pass: bit i = row valid, bit 8+i = t==0, bit 16+i = t==T-1
+    int c4;
+    __device__ __forceinline__ void init(const float* base, int64_t ld, int row0, int nrows, int tid, int convT) {
+        c4 = (tid & 7) * 4;
+        const int r0 = tid >> 3;
+        flags = 0;
 #pragma unroll
-    for (int i = 0; i < ROWS / 32; ++i) {
-        const int r = row0 + r0 + 32 * i;
-        const int k = k0 + c4;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        bool ok = (r < nrows) && (k < K);
-        if (convT > 0 && ok) ok = !conv_masked(r, k, convT, convE);
-        if (ok) v = *reinterpret_cast<const float4*>(base + (int64_t)r * ld + k);
-        reg[i] = v;
+        for (int i = 0; i < ROWS / 32; ++i) {
+            const int r = row0 + r0 + 32 * i;
+            const bool ok = r < nrows;
+            ptr[i] = base + (int64_t)(ok ? r : row0) * ld + c4;
+            if (ok) flags |= 1u << i;
+            if (convT > 0) {
+                const int t = r % convT;
+                if (t == 0) flags |= 1u << (8 + i);
+                if (t == convT - 1) flags |= 1u << (16 + i);
+            }
+        }
     }
-}
+    __device__ __forceinline__ void load(float4 (&reg)[ROWS / 32], int k0, int K, int convE) const {
+        const int k = k0 + c4;
+        const bool kok = k < K;
+        const bool seg0 = k < convE, seg2 = k >= 2 * convE;          // convE == 0 -> both false/true-but-unflagged
+#pragma unroll
+        for (int i = 0; i < ROWS / 32; ++i) {
+            bool ok = kok && ((flags >> i) & 1u);
+            if (((flags >> (8 + i)) & 1u) && seg0) ok = false;
+            if (((flags >> (16 + i)) & 1u) && seg2) ok = false;
+            reg[i] = ok ? *reinterpret_cast<const float4*>(ptr[i] + k0) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    }
+};
 template <int ROWS>
 __device__ __forceinline__ void store_kc(float* lds, const float4 (&reg)[ROWS / 32], int tid) {
     const int c4 = (tid & 7) * 4;
@@ -67,23 +89,35 @@ __device__ __forceinline__ void store_kc(float* lds, const float4 (&reg)[ROWS / 
 
 // reduction-major operand: tile 32 (k) x COLS floats
 template <int COLS>
-__device__ __forceinline__ void load_rm(float4 (&reg)[COLS / 32], const float* __restrict__ base, int64_t ld,
-                                        int col0, int ncols, int k0, int K, int tid, int convT, int convE) {
-    constexpr int TPR = COLS / 4;          // threads per k-row
-    constexpr int KPP = 256 / TPR;         // k-rows per pass
-    const int c4 = (tid % TPR) * 4;
-    const int kr0 = tid / TPR;
-#pragma unroll
-    for (int i = 0; i < COLS / 32; ++i) {
-        const int k = k0 + kr0 + KPP * i;
-        const int c = col0 + c4;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        bool ok = (k < K) && (c < ncols);
-        if (convT > 0 && ok) ok = !conv_masked(k, c, convT, convE);
-        if (ok) v = *reinterpret_cast<const float4*>(base + (int64_t)k * ld + c);
-        reg[i] = v;
+struct LoaderRM {
+    static constexpr int TPR = COLS / 4;     // threads per k-row
+    static constexpr int KPP = 256 / TPR;    // k-rows per pass
+    const float* colbase;                    // &base[c]
+    int64_t ld;
+    int kr0;
+    bool cok, seg0, seg2;
+    __device__ __forceinline__ void init(const float* base, int64_t ld_, int col0, int ncols, int tid, int convE) {
+        const int c = col0 + (tid % TPR) * 4;
+        kr0 = tid / TPR;
+        cok = c < ncols;
+        colbase = base + (cok ? c : col0);
+        ld = ld_;
+        seg0 = c < convE;
+        seg2 = convE > 0 && c >= 2 * convE;
     }
-}
+    __device__ __forceinline__ void load(float4 (&reg)[COLS / 32], int k0, int K, int convT) const {
+#pragma unroll
+        for (int i = 0; i < COLS / 32; ++i) {
+            const int k = k0 + kr0 + KPP * i;
+            bool ok = cok && (k < K);
+            if (convT > 0) {
+                const int t = k % convT;
+                if ((t == 0 && seg0) || (t == convT - 1 && seg2)) ok = false;
+            }
+            reg[i] = ok ? *reinterpret_cast<const float4*>(colbase + (int64_t)k * ld) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    }
+};
 template <int COLS>
 __device__ __forceinline__ void store_rm(float* lds, const float4 (&reg)[COLS / 32], int tid) {
     constexpr int TPR = COLS / 4;
@@ -95,27 +129,77 @@ __device__ __forceinline__ void store_rm(float* lds, const float4 (&reg)[COLS / 
         *reinterpret_cast<float4*>(lds + (kr0 + KPP * i) * RedMajor<COLS>::LD + c4) = reg[i];
 }
 
+// epilogue math on a value whose aux operands are already in registers
+template <int EPI>
+__device__ __forceinline__ float epi_math(float v, float a, float a2) {
+    if (EPI == EPI_RELU) return fmaxf(v, 0.f);
+    if (EPI == EPI_GELU) return gelu_f(v);
+    if (EPI == EPI_TANH) return tanhf(v);
+    if (EPI == EPI_ADD_AUX) return v + a;
+    if (EPI == EPI_MUL_GELU_GRAD) return v * gelu_grad_f(a);
+    if (EPI == EPI_ADD_AUX_RELUMASK) return a2 > 0.f ? v + a : 0.f;
+    if (EPI == EPI_RELUMASK) return a2 > 0.f ? v : 0.f;
+    return v;
+}
+template <int EPI> struct EpiTraits {
+    static constexpr bool AUX = EPI == EPI_ADD_AUX || EPI == EPI_MUL_GELU_GRAD || EPI == EPI_ADD_AUX_RELUMASK;
+    static constexpr bool AUX2 = EPI == EPI_ADD_AUX_RELUMASK || EPI == EPI_RELUMASK;
+};
+
 __device__ __forceinline__ float epilogue(float v, int epi, int m, int n, const GemmParams& p) {
+    const float a = (epi == EPI_ADD_AUX || epi == EPI_MUL_GELU_GRAD || epi == EPI_ADD_AUX_RELUMASK) ? p.aux[(int64_t)m * p.ldaux + n] : 0.f;
+    const float a2 = (epi == EPI_ADD_AUX_RELUMASK || epi == EPI_RELUMASK) ? p.aux2[(int64_t)m * p.ldaux2 + n] : 0.f;
     switch (epi) {
-        case EPI_NONE: return v;
-        case EPI_RELU: return fmaxf(v, 0.f);
+        case EPI_RELU: return epi_math<EPI_RELU>(v, a, a2);
         case EPI_GELU:
             if (p.out2) p.out2[(int64_t)m * p.ldout2 + n] = v;
-            return gelu_f(v);
-        case EPI_TANH: return tanhf(v);
-        case EPI_ADD_AUX: return v + p.aux[(int64_t)m * p.ldaux + n];
-        case EPI_MUL_GELU_GRAD: return v * gelu_grad_f(p.aux[(int64_t)m * p.ldaux + n]);
-        case EPI_ADD_AUX_RELUMASK: {
-            const float g = v + p.aux[(int64_t)m * p.ldaux + n];
-            return p.aux2[(int64_t)m * p.ldaux2 + n] > 0.f ? g : 0.f;
-        }
-        case EPI_RELUMASK: return p.aux2[(int64_t)m * p.ldaux2 + n] > 0.f ? v : 0.f;
+            return epi_math<EPI_GELU>(v, a, a2);
+        case EPI_TANH: return epi_math<EPI_TANH>(v, a, a2);
+        case EPI_ADD_AUX: return epi_math<EPI_ADD_AUX>(v, a, a2);
+        case EPI_MUL_GELU_GRAD: return epi_math<EPI_MUL_GELU_GRAD>(v, a, a2);
+        case EPI_ADD_AUX_RELUMASK: return epi_math<EPI_ADD_AUX_RELUMASK>(v, a, a2);
+        case EPI_RELUMASK: return epi_math<EPI_RELUMASK>(v, a, a2);
     }
     return v;
 }
 
+// write one wave's 64 x (32*NJ) accumulator block.  C/D map of the 32x32 MFMA:
+// col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5).  Aux operands of a 32x32 tile are
+// loaded as one batch BEFORE its stores (the compiler cannot prove C does not alias aux, so
+// interleaving them would serialise every element behind a full memory round trip).
+template <int EPI, int NJ, bool CHECK>
+__device__ __forceinline__ void store_block(const f32x16 (&acc)[2][NJ], float* __restrict__ C, int mw, int nw, int l31, int h,
+                                            bool use_bias, const GemmParams& p) {
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        const int n = nw + j * 32 + l31;
+        if (CHECK && n >= p.N) continue;
+        const float bv = use_bias ? p.bias[n] : 0.f;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int mb = mw + i * 32 + 4 * h;
+            float a[16], a2[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = mb + (r & 3) + 8 * (r >> 2);
+                const bool ok = !CHECK || m < p.M;
+                a[r] = (EpiTraits<EPI>::AUX && ok) ? p.aux[(int64_t)m * p.ldaux + n] : 0.f;
+                a2[r] = (EpiTraits<EPI>::AUX2 && ok) ? p.aux2[(int64_t)m * p.ldaux2 + n] : 0.f;
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = mb + (r & 3) + 8 * (r >> 2);
+                if (CHECK && m >= p.M) continue;
+                const float v = acc[i][j][r] + bv;
+                if (EPI == EPI_GELU && p.out2) p.out2[(int64_t)m * p.ldout2 + n] = v;
+                C[(int64_t)m * p.ldc + n] = epi_math<EPI>(v, a[r], a2[r]);
+            }
+        }
+    }
+}
+
 template <bool A_KC, bool B_KC, int NJ>
-__global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmParams p) {
+__global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const GemmParams p) {
     constexpr int BN = 64 * NJ;
     constexpr int A_ELEMS = A_KC ? BM * KC_LD : BK * RedMajor<BM>::LD;
     constexpr int B_ELEMS = B_KC ? BN * KC_LD : BK * RedMajor<BN>::LD;
@@ -162,13 +246,14 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmParams p) {
     float4 rb[BN / 32];
     const int convA = (p.conv_on == 1) ? p.conv_T : 0;
     const int convB = (p.conv_on == 2) ? p.conv_T : 0;
+    LoaderKC<BM> lkA; LoaderRM<BM> lrA; LoaderKC<BN> lkB; LoaderRM<BN> lrB;
+    if (A_KC) lkA.init(p.A, p.lda, m0, p.M, tid, convA); else lrA.init(p.A, p.lda, m0, p.M, tid, 0);
+    if (B_KC) lkB.init(p.B, p.ldb, n0, p.N, tid, 0);     else lrB.init(p.B, p.ldb, n0, p.N, tid, convB ? p.conv_E : 0);
 
     auto gload = [&](int kt) {
         const int k0 = kt * BK;
-        if (A_KC) load_kc<BM>(ra, p.A, p.lda, m0, p.M, k0, p.K, tid, convA, p.conv_E);
-        else      load_rm<BM>(ra, p.A, p.lda, m0, p.M, k0, p.K, tid, 0, 0);
-        if (B_KC) load_kc<BN>(rb, p.B, p.ldb, n0, p.N, k0, p.K, tid, 0, 0);
-        else      load_rm<BN>(rb, p.B, p.ldb, n0, p.N, k0, p.K, tid, convB, p.conv_E);
+        if (A_KC) lkA.load(ra, k0, p.K, convA ? p.conv_E : 0); else lrA.load(ra, k0, p.K, 0);
+        if (B_KC) lkB.load(rb, k0, p.K, 0);                    else lrB.load(rb, k0, p.K, convB);
     };
     auto lstore = [&](int buf) {
         if (A_KC) store_kc<BM>(As + buf * A_ELEMS, ra, tid);
@@ -236,26 +321,29 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmParams p) {
         cur ^= 1;
     }
 
-    // ---- epilogue: C/D map col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+    // ---- epilogue (one switch per wave, straight-line stores inside)
     const bool partial = p.ksplit > 1;
     float* Cout = partial ? p.C + (int64_t)ks * p.split_stride : p.C;
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-#pragma unroll
-        for (int j = 0; j < NJ; ++j) {
-            const int n = n0 + wc * (BN / 2) + j * 32 + l31;
-            if (n >= p.N) continue;
-            const float bv = (!partial && p.bias) ? p.bias[n] : 0.f;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int m = m0 + wr * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                if (m >= p.M) continue;
-                float v = acc[i][j][r] + bv;
-                if (!partial) v = epilogue(v, p.epi, m, n, p);
-                Cout[(int64_t)m * p.ldc + n] = v;
-            }
-        }
+    const int mw = m0 + wr * 64, nw = n0 + wc * (BN / 2);
+    const bool full = (mw + 64 <= p.M) && (nw + BN / 2 <= p.N);
+    const bool ub = !partial && p.bias != nullptr;
+    const int epi = partial ? EPI_NONE : p.epi;
+#define NR_STORE(E)                                                                        \
+    do {                                                                                   \
+        if (full) store_block<E, NJ, false>(acc, Cout, mw, nw, l31, h, ub, p);             \
+        else      store_block<E, NJ, true>(acc, Cout, mw, nw, l31, h, ub, p);              \
+    } while (0)
+    switch (epi) {
+        case EPI_NONE: NR_STORE(EPI_NONE); break;
+        case EPI_RELU: NR_STORE(EPI_RELU); break;
+        case EPI_GELU: NR_STORE(EPI_GELU); break;
+        case EPI_TANH: NR_STORE(EPI_TANH); break;
+        case EPI_ADD_AUX: NR_STORE(EPI_ADD_AUX); break;
+        case EPI_MUL_GELU_GRAD: NR_STORE(EPI_MUL_GELU_GRAD); break;
+        case EPI_ADD_AUX_RELUMASK: NR_STORE(EPI_ADD_AUX_RELUMASK); break;
+        case EPI_RELUMASK: NR_STORE(EPI_RELUMASK); break;
     }
+#undef NR_STORE
 }
 
 // sum split-K slabs (fixed order -> deterministic), add bias, apply epilogue

@@ -10,6 +10,13 @@ int mhsa_fwd(const float* qkv, const int64_t* mask, float* ctx, float* row_max, 
 int mhsa_bwd(const float* qkv, const int64_t* mask, const float* ctx, const float* dctx, const float* row_max,
              const float* row_sum, float* dqkv, int64_t N, int S, int H, int dh, DropoutCfg dc, hipStream_t s);
 
+// title-length fast path on the f32 matrix cores (attention_mfma.hip): S <= 32, dh <= 64
+bool mhsa_mfma_supported(int S, int dh);
+int mhsa_fwd_mfma(const float* qkv, const int64_t* mask, float* ctx, float* row_max, float* row_sum, int64_t N, int S, int H,
+                  int dh, DropoutCfg dc, hipStream_t s);
+int mhsa_bwd_mfma(const float* qkv, const int64_t* mask, const float* dctx, const float* row_max, const float* row_sum,
+                  float* dqkv, int64_t N, int S, int H, int dh, DropoutCfg dc, hipStream_t s);
+
 int pool_fwd(const float* key, const float* value, const float* table, const int64_t* idx, int64_t nrows, const float* query,
              const int64_t* mask, float* out, float* prob, int64_t nseq, int S, int D, hipStream_t s);
 int pool_bwd(const float* key, const float* value, const float* query, const float* prob, const float* dout, float* dkeypre,
