@@ -1,5 +1,6 @@
 // Multi-head self-attention for title-length sequences (S <= 32, dh <= 64) on the f32 matrix cores.
-// One wave per (sequence, head); the whole head is one 32x32 score tile.
+// One 256-thread workgroup per (sequence, group of 4 heads); one wave per head; a head is one 32x32
+// score tile.
 //
 // Orientation trick (v_mfma_f32_32x32x2_f32: lane l feeds A[i=l&31][k=l>>5], B[k=l>>5][j=l&31];
 // the result puts column j on the lane and 16 rows in registers, row(r,h) = (r&3)+8(r>>2)+4h):
@@ -11,7 +12,12 @@
 //       dK^T = Q^T . dS       dV^T = dO^T . Pd           (from the "N" tiles S = Q.K^T, row = query)
 //   so no P / dS tile ever moves between lanes or through LDS.  The backward recomputes both
 //   orientations (13 MFMAs each at dh = 25) from the saved per-query softmax max/sum.
+// HBM access: the 4 heads of a group are 4*dh contiguous floats of every qkv row, so the workgroup
+// moves [S rows] x [4*dh] segments as 16-byte vectors (400-B runs at dh = 25) and scatters them into
+// per-head LDS tiles; results leave the same way.
 // Score arithmetic is the reference's: x = fl32(q.k / sqrt(dh)) + (1-mask_key)*(-1e5); p = exp(x-max)/sum.
+// Dropout keep bits are drawn once, in the T orientation (4 consecutive keys share one Philox call
+// when S % 4 == 0), and handed to the N orientation as a 32-bit word per query through LDS.
 #include "common.h"
 #include "seqops.h"
 
@@ -19,28 +25,84 @@ namespace nr {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 constexpr float MASK_FILL_M = -1e5f;
+constexpr int HPG = 4;                 // heads per workgroup
 
 __device__ __forceinline__ int krow(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
+__device__ __forceinline__ int fastdiv(int x, int inv20) { return (int)(((unsigned)x * (unsigned)inv20) >> 20); }   // x < 16384/d
 
-// [S, dh] global tile (row stride ld) -> LDS [32][LD] zero padded (rows >= S, cols >= dh)
+// zero what the MFMAs read but the copy does not write: rows >= S, and the odd-dh pad column
 template <int DHP>
-__device__ __forceinline__ void tile_in(float* lds, const float* __restrict__ g, int64_t ld, int S, int dh, int lane) {
+__device__ __forceinline__ void tile_zero_pad(float* tile, int S, int dh, int lane) {
     constexpr int LD = DHP + 1;
-    for (int idx = lane; idx < 32 * DHP; idx += 64) {
-        const int r = idx / DHP, d = idx - r * DHP;
-        lds[r * LD + d] = (r < S && d < dh) ? g[(int64_t)r * ld + d] : 0.f;
-    }
-}
-template <int DHP>
-__device__ __forceinline__ void tile_out(float* __restrict__ g, int64_t ld, const float* lds, int S, int dh, int lane) {
-    constexpr int LD = DHP + 1;
-    for (int idx = lane; idx < S * dh; idx += 64) {
-        const int r = idx / dh, d = idx - r * dh;
-        g[(int64_t)r * ld + d] = lds[r * LD + d];
+    const int dz = ((dh + 1) >> 1) * 2;          // columns read by the d-step loop
+    if (dz > dh && lane < 32) tile[lane * LD + dh] = 0.f;
+    for (int idx = lane; idx < (32 - S) * dz; idx += 64) {
+        const int r = S + idx / dz, c = idx - (idx / dz) * dz;
+        tile[r * LD + c] = 0.f;
     }
 }
 
-// acc[r] (+)= sum_d X[row(r,h)][d] * Y[l31][d]  i.e. tile = X . Y^T with row = X's row, col = Y's row
+// [S rows] x [nh*dh] global segment (row stride ld) -> nh per-head tiles [32][LD]
+template <int DHP>
+__device__ __forceinline__ void heads_in(float* tiles, const float* __restrict__ g, int64_t ld, int S, int dh, int nh, int tid, bool vec) {
+    constexpr int LD = DHP + 1, TS = 32 * LD;
+    const int W = nh * dh;
+    const int inv_dh = (1048576 + dh - 1) / dh;
+    if (vec) {
+        const int nq = W >> 2;
+        const int inv_nq = (1048576 + nq - 1) / nq;
+        for (int idx = tid; idx < S * nq; idx += 256) {
+            const int r = fastdiv(idx, inv_nq);
+            const int c = (idx - r * nq) << 2;
+            const float4 v = *reinterpret_cast<const float4*>(g + (int64_t)r * ld + c);
+            int hh = fastdiv(c, inv_dh), d = c - hh * dh;
+            const float e[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                tiles[hh * TS + r * LD + d] = e[k];
+                if (++d == dh) { d = 0; ++hh; }
+            }
+        }
+    } else {
+        for (int idx = tid; idx < S * W; idx += 256) {
+            const int r = idx / W;
+            const int c = idx - r * W;
+            const int hh = fastdiv(c, inv_dh);
+            tiles[hh * TS + r * LD + (c - hh * dh)] = g[(int64_t)r * ld + c];
+        }
+    }
+}
+template <int DHP>
+__device__ __forceinline__ void heads_out(float* __restrict__ g, int64_t ld, const float* tiles, int S, int dh, int nh, int tid, bool vec) {
+    constexpr int LD = DHP + 1, TS = 32 * LD;
+    const int W = nh * dh;
+    const int inv_dh = (1048576 + dh - 1) / dh;
+    if (vec) {
+        const int nq = W >> 2;
+        const int inv_nq = (1048576 + nq - 1) / nq;
+        for (int idx = tid; idx < S * nq; idx += 256) {
+            const int r = fastdiv(idx, inv_nq);
+            const int c = (idx - r * nq) << 2;
+            int hh = fastdiv(c, inv_dh), d = c - hh * dh;
+            float e[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                e[k] = tiles[hh * TS + r * LD + d];
+                if (++d == dh) { d = 0; ++hh; }
+            }
+            *reinterpret_cast<float4*>(g + (int64_t)r * ld + c) = make_float4(e[0], e[1], e[2], e[3]);
+        }
+    } else {
+        for (int idx = tid; idx < S * W; idx += 256) {
+            const int r = idx / W;
+            const int c = idx - r * W;
+            const int hh = fastdiv(c, inv_dh);
+            g[(int64_t)r * ld + c] = tiles[hh * TS + r * LD + (c - hh * dh)];
+        }
+    }
+}
+
+// acc[r] = sum_d X[row(r,h)][d] * Y[l31][d]  i.e. tile = X . Y^T with row = X's row, col = Y's row
 template <int DHP>
 __device__ __forceinline__ f32x16 tile_xyT(const float* Xs, const float* Ys, int dsteps, int l31, int h) {
     constexpr int LD = DHP + 1;
@@ -78,115 +140,168 @@ __device__ __forceinline__ void put_T(float* Ts, const f32x16& o, int dt, int l3
     for (int r = 0; r < 16; ++r) Ts[l31 * LD + dt * 32 + krow(r, h)] = o[r];
 }
 
-__device__ __forceinline__ float keep_of(const DropoutCfg& dc, uint32_t thr, float scale, uint64_t idx) {
-    const Philox4 rn = philox4x32_10(dc.seed, idx >> 2, dc.site);
-    return philox_pick(rn, (int)(idx & 3)) >= thr ? scale : 0.f;
+// keep flags (bit r = keep element krow(r,h)) of query row `qrow` for this lane's 16 keys
+__device__ __forceinline__ unsigned keep_bits16(const DropoutCfg& dc, uint32_t thr, int64_t qrow, int S, int h) {
+    unsigned bits = 0;
+    if ((S & 3) == 0) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {                       // keys 8q+4h .. +3 share one Philox counter
+            const uint64_t idx = (uint64_t)(qrow * S + 8 * q + 4 * h);
+            const Philox4 rn = philox4x32_10(dc.seed, idx >> 2, dc.site);
+            bits |= (rn.x >= thr ? 1u : 0u) << (4 * q);
+            bits |= (rn.y >= thr ? 1u : 0u) << (4 * q + 1);
+            bits |= (rn.z >= thr ? 1u : 0u) << (4 * q + 2);
+            bits |= (rn.w >= thr ? 1u : 0u) << (4 * q + 3);
+        }
+    } else {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const uint64_t idx = (uint64_t)(qrow * S + krow(r, h));
+            const Philox4 rn = philox4x32_10(dc.seed, idx >> 2, dc.site);
+            bits |= (philox_pick(rn, (int)(idx & 3)) >= thr ? 1u : 0u) << r;
+        }
+    }
+    return bits;
 }
 
 template <int DHP>
-__global__ __launch_bounds__(64) void mhsa_fwd_mfma_kernel(const float* __restrict__ qkv, const int64_t* __restrict__ mask,
-                                                           float* __restrict__ ctx, float* __restrict__ row_max,
-                                                           float* __restrict__ row_sum, int S, int H, int dh, DropoutCfg dc) {
-    constexpr int LD = DHP + 1;
+__global__ __launch_bounds__(256) void mhsa_fwd_mfma_kernel(const float* __restrict__ qkv, const int64_t* __restrict__ mask,
+                                                            float* __restrict__ ctx, float* __restrict__ row_max,
+                                                            float* __restrict__ row_sum, int S, int H, int dh, DropoutCfg dc,
+                                                            int vec) {
+    constexpr int LD = DHP + 1, TS = 32 * LD;
     constexpr int DT = DHP / 32;
-    __shared__ float Qs[32 * LD], Ks[32 * LD], Vs[32 * LD];
-    const int lane = threadIdx.x, l31 = lane & 31, h = lane >> 5;
-    const int n = blockIdx.x / H, hd = blockIdx.x - n * H;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* Qt = smem;                  // [HPG][TS]  (reused for the output tiles)
+    float* Kt = Qt + HPG * TS;
+    float* Vt = Kt + HPG * TS;
+    const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63, l31 = lane & 31, h = lane >> 5;
+    const int groups = (H + HPG - 1) / HPG;
+    const int n = blockIdx.x / groups, gidx = blockIdx.x - n * groups;
+    const int hd0 = gidx * HPG, nh = min(HPG, H - hd0), hd = hd0 + w;
+    const bool active = w < nh;
     const int A = H * dh;
     const int64_t ld = 3 * (int64_t)A;
-    const float* base = qkv + (int64_t)n * S * ld + hd * dh;
-    tile_in<DHP>(Qs, base, ld, S, dh, lane);
-    tile_in<DHP>(Ks, base + A, ld, S, dh, lane);
-    tile_in<DHP>(Vs, base + 2 * A, ld, S, dh, lane);
+    const float* base = qkv + (int64_t)n * S * ld + hd0 * dh;
+    heads_in<DHP>(Qt, base, ld, S, dh, nh, tid, vec);
+    heads_in<DHP>(Kt, base + A, ld, S, dh, nh, tid, vec);
+    heads_in<DHP>(Vt, base + 2 * A, ld, S, dh, nh, tid, vec);
+    float* Qs = Qt + w * TS; float* Ks = Kt + w * TS; float* Vs = Vt + w * TS;
+    if (active) { tile_zero_pad<DHP>(Qs, S, dh, lane); tile_zero_pad<DHP>(Ks, S, dh, lane); tile_zero_pad<DHP>(Vs, S, dh, lane); }
     __syncthreads();
-    const int dsteps = (dh + 1) >> 1;
-    const float sq = sqrtf((float)dh);
-
-    f32x16 st = tile_xyT<DHP>(Ks, Qs, dsteps, l31, h);       // row = key, col = query (this lane's query = l31)
-    float m = -INFINITY;
+    f32x16 st;
+    if (active) {
+        const int dsteps = (dh + 1) >> 1;
+        const float sq = sqrtf((float)dh);
+        st = tile_xyT<DHP>(Ks, Qs, dsteps, l31, h);           // row = key, col = query (this lane's query = l31)
+        float m = -INFINITY;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int j = krow(r, h);
-        float x = st[r] / sq;
-        x += (j < S) ? (mask[(int64_t)n * S + j] ? 0.f : MASK_FILL_M) : -INFINITY;
-        st[r] = x;
-        m = fmaxf(m, x);
+        for (int r = 0; r < 16; ++r) {
+            const int j = krow(r, h);
+            float x = st[r] / sq;
+            x += (j < S) ? (mask[(int64_t)n * S + j] ? 0.f : MASK_FILL_M) : -INFINITY;
+            st[r] = x;
+            m = fmaxf(m, x);
+        }
+        m = fmaxf(m, __shfl_xor(m, 32, 64));
+        float sum = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float e = expf(st[r] - m);
+            st[r] = e;
+            sum += e;
+        }
+        sum += __shfl_xor(sum, 32, 64);
+        const int64_t qrow = ((int64_t)n * H + hd) * S + l31;
+        if (row_max && h == 0 && l31 < S) { row_max[qrow] = m; row_sum[qrow] = sum; }
+        unsigned bits = 0xFFFFu;
+        float scale = 1.f;
+        if (dc.p > 0.f) { bits = keep_bits16(dc, drop_threshold(dc.p), qrow, S, h); scale = 1.0f / (1.0f - dc.p); }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            float p = st[r] / sum;
+            if (dc.p > 0.f) p = ((bits >> r) & 1u) ? p * scale : 0.f;
+            st[r] = p;
+        }
     }
-    m = fmaxf(m, __shfl_xor(m, 32, 64));
-    float sum = 0.f;
+    __syncthreads();                                           // all waves are done reading the Q tiles
+    if (active) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const float e = expf(st[r] - m);
-        st[r] = e;
-        sum += e;
-    }
-    sum += __shfl_xor(sum, 32, 64);
-    const int64_t qrow = ((int64_t)n * H + hd) * S + l31;
-    if (row_max && h == 0 && l31 < S) { row_max[qrow] = m; row_sum[qrow] = sum; }
-    const uint32_t thr = drop_threshold(dc.p);
-    const float scale = dc.p > 0.f ? 1.0f / (1.0f - dc.p) : 1.0f;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        float p = st[r] / sum;
-        if (dc.p > 0.f) p *= keep_of(dc, thr, scale, (uint64_t)(qrow * S + krow(r, h)));
-        st[r] = p;
-    }
-    __syncthreads();                                           // every lane is done reading Qs
-#pragma unroll
-    for (int dt = 0; dt < DT; ++dt) {
-        const f32x16 o = zT_tile<DHP>(Vs, st, dt, l31, h);     // O^T[d][query]
-        put_T<DHP>(Qs, o, dt, l31, h);
+        for (int dt = 0; dt < DT; ++dt) {
+            const f32x16 o = zT_tile<DHP>(Vs, st, dt, l31, h);     // O^T[d][query]
+            put_T<DHP>(Qs, o, dt, l31, h);
+        }
     }
     __syncthreads();
-    tile_out<DHP>(ctx + (int64_t)n * S * A + hd * dh, A, Qs, S, dh, lane);
+    heads_out<DHP>(ctx + (int64_t)n * S * A + hd0 * dh, A, Qt, S, dh, nh, tid, vec);
 }
 
 template <int DHP>
-__global__ __launch_bounds__(64) void mhsa_bwd_mfma_kernel(const float* __restrict__ qkv, const int64_t* __restrict__ mask,
-                                                           const float* __restrict__ dctx, const float* __restrict__ row_max,
-                                                           const float* __restrict__ row_sum, float* __restrict__ dqkv,
-                                                           int S, int H, int dh, DropoutCfg dc) {
-    constexpr int LD = DHP + 1;
+__global__ __launch_bounds__(256) void mhsa_bwd_mfma_kernel(const float* __restrict__ qkv, const int64_t* __restrict__ mask,
+                                                            const float* __restrict__ dctx, const float* __restrict__ row_max,
+                                                            const float* __restrict__ row_sum, float* __restrict__ dqkv,
+                                                            int S, int H, int dh, DropoutCfg dc, int vec) {
+    constexpr int LD = DHP + 1, TS = 32 * LD;
     constexpr int DT = DHP / 32;
-    __shared__ float Qs[32 * LD], Ks[32 * LD], Vs[32 * LD], Gs[32 * LD], Ts[32 * LD];
-    __shared__ float Ms[32], Ls[32], Dsh[32], Mk[32];
-    const int lane = threadIdx.x, l31 = lane & 31, h = lane >> 5;
-    const int n = blockIdx.x / H, hd = blockIdx.x - n * H;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* Qt = smem;
+    float* Kt = Qt + HPG * TS;
+    float* Vt = Kt + HPG * TS;
+    float* Gt = Vt + HPG * TS;
+    float* St = Gt + HPG * TS;          // [HPG][4][32]: max, sum, D, key-mask term ; then [HPG][32] keep words
+    const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63, l31 = lane & 31, h = lane >> 5;
+    const int groups = (H + HPG - 1) / HPG;
+    const int n = blockIdx.x / groups, gidx = blockIdx.x - n * groups;
+    const int hd0 = gidx * HPG, nh = min(HPG, H - hd0), hd = hd0 + w;
+    const bool active = w < nh;
     const int A = H * dh;
     const int64_t ld = 3 * (int64_t)A;
-    const float* base = qkv + (int64_t)n * S * ld + hd * dh;
-    tile_in<DHP>(Qs, base, ld, S, dh, lane);
-    tile_in<DHP>(Ks, base + A, ld, S, dh, lane);
-    tile_in<DHP>(Vs, base + 2 * A, ld, S, dh, lane);
-    tile_in<DHP>(Gs, dctx + (int64_t)n * S * A + hd * dh, A, S, dh, lane);
+    const float* base = qkv + (int64_t)n * S * ld + hd0 * dh;
+    heads_in<DHP>(Qt, base, ld, S, dh, nh, tid, vec);
+    heads_in<DHP>(Kt, base + A, ld, S, dh, nh, tid, vec);
+    heads_in<DHP>(Vt, base + 2 * A, ld, S, dh, nh, tid, vec);
+    heads_in<DHP>(Gt, dctx + (int64_t)n * S * A + hd0 * dh, A, S, dh, nh, tid, vec);
+    float* Qs = Qt + w * TS; float* Ks = Kt + w * TS; float* Vs = Vt + w * TS; float* Gs = Gt + w * TS;
+    float* Ms = St + w * 128; float* Ls = Ms + 32; float* Dsh = Ms + 64; float* Mk = Ms + 96;
+    unsigned* Kb = reinterpret_cast<unsigned*>(St + HPG * 128) + w * 32;
     const int64_t qrow0 = ((int64_t)n * H + hd) * S;
-    if (lane < 32) {
-        const bool ok = lane < S;
-        Ms[lane] = ok ? row_max[qrow0 + lane] : 0.f;
-        Ls[lane] = ok ? row_sum[qrow0 + lane] : 1.f;
-        Mk[lane] = ok ? (mask[(int64_t)n * S + lane] ? 0.f : MASK_FILL_M) : -INFINITY;
+    if (active) {
+        tile_zero_pad<DHP>(Qs, S, dh, lane); tile_zero_pad<DHP>(Ks, S, dh, lane);
+        tile_zero_pad<DHP>(Vs, S, dh, lane); tile_zero_pad<DHP>(Gs, S, dh, lane);
+        if (lane < 32) {
+            const bool ok = lane < S;
+            Ms[lane] = ok ? row_max[qrow0 + lane] : 0.f;
+            Ls[lane] = ok ? row_sum[qrow0 + lane] : 1.f;
+            Mk[lane] = ok ? (mask[(int64_t)n * S + lane] ? 0.f : MASK_FILL_M) : -INFINITY;
+        }
     }
     __syncthreads();
     const int dsteps = (dh + 1) >> 1;
     const float sq = sqrtf((float)dh);
-    const uint32_t thr = drop_threshold(dc.p);
     const float scale = dc.p > 0.f ? 1.0f / (1.0f - dc.p) : 1.0f;
-    float* dbase = dqkv + (int64_t)n * S * ld + hd * dh;
-
-    // ---------------- T orientation: row = key, col = query (lane's query = l31)
-    {
+    f32x16 dq[DT], ds, pdn;
+    if (active) {
+        // ---------------- T orientation: row = key, col = query (lane's query = l31)
         f32x16 st = tile_xyT<DHP>(Ks, Qs, dsteps, l31, h);
-        f32x16 dpt = tile_xyT<DHP>(Vs, Gs, dsteps, l31, h);   // dPd^T[key][query] = V[key].dO[query]
+        const f32x16 dpt = tile_xyT<DHP>(Vs, Gs, dsteps, l31, h);   // dPd^T[key][query] = V[key].dO[query]
         const float m = Ms[l31], sum = Ls[l31];
+        unsigned bits = 0xFFFFu;
+        if (dc.p > 0.f) {
+            bits = keep_bits16(dc, drop_threshold(dc.p), qrow0 + l31, S, h);
+            // 32-bit keep word of query l31: bit j = keep key j  (register r of half h is key krow(r,h))
+            unsigned word = 0;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) word |= ((bits >> r) & 1u) << krow(r, h);
+            word |= __shfl_xor(word, 32, 64);
+            if (h == 0) Kb[l31] = word;
+        }
         float pr[16];
         float dpart = 0.f;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const int j = krow(r, h);
-            const float x = st[r] / sq + Mk[j];
+            const float x = st[r] / sq + Mk[krow(r, h)];
             const float p = expf(x - m) / sum;
-            float pd = p;
-            if (dc.p > 0.f) pd *= keep_of(dc, thr, scale, (uint64_t)((qrow0 + l31) * S + j));
+            const float pd = (dc.p > 0.f) ? (((bits >> r) & 1u) ? p * scale : 0.f) : p;
             pr[r] = p;
             st[r] = pd * dpt[r];                               // Pd * dPd
             dpart += st[r];
@@ -196,16 +311,11 @@ __global__ __launch_bounds__(64) void mhsa_bwd_mfma_kernel(const float* __restri
 #pragma unroll
         for (int r = 0; r < 16; ++r) st[r] = (st[r] - pr[r] * D) / sq;      // dS^T
 #pragma unroll
-        for (int dt = 0; dt < DT; ++dt) {
-            const f32x16 o = zT_tile<DHP>(Ks, st, dt, l31, h);              // dQ^T[d][query]
-            put_T<DHP>(Ts, o, dt, l31, h);
-        }
+        for (int dt = 0; dt < DT; ++dt) dq[dt] = zT_tile<DHP>(Ks, st, dt, l31, h);   // dQ^T[d][query], kept in registers
     }
-    __syncthreads();
-    tile_out<DHP>(dbase, ld, Ts, S, dh, lane);
-    // ---------------- N orientation: row = query, col = key (lane's key = l31)
-    f32x16 ds, pdn;
-    {
+    __syncthreads();                                           // Dsh / Kb visible (same wave, but keep it simple)
+    if (active) {
+        // ---------------- N orientation: row = query, col = key (lane's key = l31)
         ds = tile_xyT<DHP>(Qs, Ks, dsteps, l31, h);
         const f32x16 dpn = tile_xyT<DHP>(Gs, Vs, dsteps, l31, h);
         const float mk = Mk[l31];
@@ -215,44 +325,78 @@ __global__ __launch_bounds__(64) void mhsa_bwd_mfma_kernel(const float* __restri
             const float x = ds[r] / sq + mk;
             const float p = expf(x - Ms[i]) / Ls[i];
             float pd = p;
-            if (dc.p > 0.f) pd *= keep_of(dc, thr, scale, (uint64_t)((qrow0 + i) * S + l31));
+            if (dc.p > 0.f) pd = ((Kb[i] >> l31) & 1u) ? p * scale : 0.f;
             pdn[r] = pd;
             ds[r] = (pd * dpn[r] - p * Dsh[i]) / sq;           // dS[query][key]
         }
     }
-    __syncthreads();                                           // Ts free again (dq copied out)
+    __syncthreads();                                           // K and V tiles are dead: reuse them as staging
+    float* dbase = dqkv + (int64_t)n * S * ld + hd0 * dh;
+    if (active) {
 #pragma unroll
-    for (int dt = 0; dt < DT; ++dt) {
-        const f32x16 o = zT_tile<DHP>(Qs, ds, dt, l31, h);     // dK^T[d][key]
-        put_T<DHP>(Ts, o, dt, l31, h);
+        for (int dt = 0; dt < DT; ++dt) {
+            put_T<DHP>(Ks, dq[dt], dt, l31, h);
+            const f32x16 o = zT_tile<DHP>(Qs, ds, dt, l31, h);     // dK^T[d][key]
+            put_T<DHP>(Vs, o, dt, l31, h);
+        }
     }
     __syncthreads();
-    tile_out<DHP>(dbase + A, ld, Ts, S, dh, lane);
+    heads_out<DHP>(dbase, ld, Kt, S, dh, nh, tid, vec);
+    heads_out<DHP>(dbase + A, ld, Vt, S, dh, nh, tid, vec);
     __syncthreads();
+    if (active) {
 #pragma unroll
-    for (int dt = 0; dt < DT; ++dt) {
-        const f32x16 o = zT_tile<DHP>(Gs, pdn, dt, l31, h);    // dV^T[d][key]
-        put_T<DHP>(Ts, o, dt, l31, h);
+        for (int dt = 0; dt < DT; ++dt) {
+            const f32x16 o = zT_tile<DHP>(Gs, pdn, dt, l31, h);    // dV^T[d][key]
+            put_T<DHP>(Ks, o, dt, l31, h);
+        }
     }
     __syncthreads();
-    tile_out<DHP>(dbase + 2 * A, ld, Ts, S, dh, lane);
+    heads_out<DHP>(dbase + 2 * A, ld, Kt, S, dh, nh, tid, vec);
 }
 
 bool mhsa_mfma_supported(int S, int dh) { return S >= 1 && S <= 32 && dh >= 1 && dh <= 64; }
 
+static bool vec_ok(const void* a, const void* b, int H, int dh) {
+    // 16-byte segments: 4 heads start on a 16-B boundary iff the row pitch and the q/k/v offsets do
+    const int A = H * dh;
+    return (A % 4 == 0) && (((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b)) & 15) == 0) &&
+           (H % HPG == 0 || (dh % 4 == 0));
+}
+
 int mhsa_fwd_mfma(const float* qkv, const int64_t* mask, float* ctx, float* row_max, float* row_sum, int64_t N, int S, int H,
                   int dh, DropoutCfg dc, hipStream_t s) {
-    const dim3 grid((unsigned)(N * H));
-    if (dh <= 32) hipLaunchKernelGGL(mhsa_fwd_mfma_kernel<32>, grid, dim3(64), 0, s, qkv, mask, ctx, row_max, row_sum, S, H, dh, dc);
-    else          hipLaunchKernelGGL(mhsa_fwd_mfma_kernel<64>, grid, dim3(64), 0, s, qkv, mask, ctx, row_max, row_sum, S, H, dh, dc);
+    const int groups = (H + HPG - 1) / HPG;
+    const dim3 grid((unsigned)(N * groups));
+    const int vec = vec_ok(qkv, ctx, H, dh) ? 1 : 0;
+    const int dhp = dh <= 32 ? 32 : 64;
+    const size_t lds = (size_t)3 * HPG * 32 * (dhp + 1) * sizeof(float);
+    if (dhp == 32) {
+        hipLaunchKernelGGL(mhsa_fwd_mfma_kernel<32>, grid, dim3(256), lds, s, qkv, mask, ctx, row_max, row_sum, S, H, dh, dc, vec);
+    } else {
+        static bool once = false;
+        if (!once) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mhsa_fwd_mfma_kernel<64>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); once = true; }
+        hipLaunchKernelGGL(mhsa_fwd_mfma_kernel<64>, grid, dim3(256), lds, s, qkv, mask, ctx, row_max, row_sum, S, H, dh, dc, vec);
+    }
     return check_launch("mhsa_fwd_mfma");
 }
 
 int mhsa_bwd_mfma(const float* qkv, const int64_t* mask, const float* dctx, const float* row_max, const float* row_sum,
                   float* dqkv, int64_t N, int S, int H, int dh, DropoutCfg dc, hipStream_t s) {
-    const dim3 grid((unsigned)(N * H));
-    if (dh <= 32) hipLaunchKernelGGL(mhsa_bwd_mfma_kernel<32>, grid, dim3(64), 0, s, qkv, mask, dctx, row_max, row_sum, dqkv, S, H, dh, dc);
-    else          hipLaunchKernelGGL(mhsa_bwd_mfma_kernel<64>, grid, dim3(64), 0, s, qkv, mask, dctx, row_max, row_sum, dqkv, S, H, dh, dc);
+    const int groups = (H + HPG - 1) / HPG;
+    const dim3 grid((unsigned)(N * groups));
+    const int vec = (vec_ok(qkv, dctx, H, dh) && vec_ok(dqkv, dqkv, H, dh)) ? 1 : 0;
+    const int dhp = dh <= 32 ? 32 : 64;
+    const size_t lds = ((size_t)4 * HPG * 32 * (dhp + 1) + HPG * 128 + HPG * 32) * sizeof(float);
+    if (dhp == 32) {
+        static bool once = false;
+        if (!once) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mhsa_bwd_mfma_kernel<32>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); once = true; }
+        hipLaunchKernelGGL(mhsa_bwd_mfma_kernel<32>, grid, dim3(256), lds, s, qkv, mask, dctx, row_max, row_sum, dqkv, S, H, dh, dc, vec);
+    } else {
+        static bool once = false;
+        if (!once) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mhsa_bwd_mfma_kernel<64>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); once = true; }
+        hipLaunchKernelGGL(mhsa_bwd_mfma_kernel<64>, grid, dim3(256), lds, s, qkv, mask, dctx, row_max, row_sum, dqkv, S, H, dh, dc, vec);
+    }
     return check_launch("mhsa_bwd_mfma");
 }
 
