@@ -8,9 +8,17 @@
 //   B_KC : B(n,k) = B[n*ldb + k]   (nn.Linear weight [N,K])
 //  !B_KC : B(n,k) = B[k*ldb + n]   (weight used transposed for dX; X for dW)
 //
-// Block: 256 threads = 4 waves (2x2), tile 128 x (64*NJ... BN) x 32, LDS double
-// buffered with register prefetch (one barrier per k-tile).  Each wave owns a
-// 64 x (BN/2) sub-tile = 2 x NJ MFMA tiles of 32x32 (acc in 32*NJ registers).
+// Block: 256 threads = 4 waves (2x2).  Each wave owns a (32*WM) x (32*NJ) sub-tile = WM x NJ MFMA
+// tiles of 32x32, so the workgroup tile is (64*WM) x (64*NJ) x 32:
+//   WM=2 NJ=1  128 x  64   activations x weights with N in {300, 900, 1200} (64 wastes least columns)
+//   WM=2 NJ=2  128 x 128   N a multiple of 128
+//   WM=5 NJ=1  320 x  64   dW = dY^T X: M is 300/900/1200 (one/three/four tiles, 6.7 % padding instead of
+//                          up to 28 % with 128-row tiles) and it issues 4.8 instead of 6 global loads per 32 MFMAs
+// One LDS buffer + register prefetch of the next k-tile (more workgroups per CU beat double buffering
+// here), LDS fragments software-pipelined by hand one k-quad ahead of the MFMAs.  Measured on MI355X
+// (tools/peaks.hip): a wave's global loads cost matrix-pipe time by themselves (2 dwordx4 loads per
+// 32 MFMAs: 156 -> 129 TFLOP/s with no data dependence at all), so loads per MFMA is the quantity the
+// tile shapes minimise.
 // K-contiguous tiles live in LDS as [row][32+4] and are read with ds_read_b128
 // (lane half h takes k = 8*kq+4*h .. +3: the k permutation is free because
 // both operands use the same one); reduction-major tiles live as [k][cols+4]
@@ -26,7 +34,6 @@ namespace nr {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int BM = 128;
 constexpr int BK = 32;
 constexpr int KC_LD = BK + 4;        // floats per LDS row of a k-contiguous tile
 
@@ -46,24 +53,30 @@ __device__ __forceinline__ bool conv_masked(int r, int c, int T, int E) {
 template <int ROWS>
 struct LoaderKC {
     const float* ptr[ROWS / 32];   // &base[row*ld + c4]
-    unsigned flags;                // per pass: bit i = row valid, bit 8+i = t==0, bit 16+i = t==T-1
+    unsigned valid, first, last;   // per pass i, bit i: row valid / conv t==0 / conv t==T-1
     int c4;
     __device__ __forceinline__ void init(const float* base, int64_t ld, int row0, int nrows, int tid, int convT) {
         c4 = (tid & 7) * 4;
         const int r0 = tid >> 3;
-        flags = 0;
+        valid = first = last = 0;
 #pragma unroll
         for (int i = 0; i < ROWS / 32; ++i) {
             const int r = row0 + r0 + 32 * i;
             const bool ok = r < nrows;
             ptr[i] = base + (int64_t)(ok ? r : row0) * ld + c4;
-            if (ok) flags |= 1u << i;
+            if (ok) valid |= 1u << i;
             if (convT > 0) {
                 const int t = r % convT;
-                if (t == 0) flags |= 1u << (8 + i);
-                if (t == convT - 1) flags |= 1u << (16 + i);
+                if (t == 0) first |= 1u << i;
+                if (t == convT - 1) last |= 1u << i;
             }
         }
+    }
+    // full k-tile, no conv: rows past the edge read a clamped (valid) row; their products land in
+    // output rows/cols that are never stored, so no predication is needed
+    __device__ __forceinline__ void load_full(float4 (&reg)[ROWS / 32], int k0) const {
+#pragma unroll
+        for (int i = 0; i < ROWS / 32; ++i) reg[i] = *reinterpret_cast<const float4*>(ptr[i] + k0);
     }
     __device__ __forceinline__ void load(float4 (&reg)[ROWS / 32], int k0, int K, int convE) const {
         const int k = k0 + c4;
@@ -71,9 +84,9 @@ struct LoaderKC {
         const bool seg0 = k < convE, seg2 = k >= 2 * convE;          // convE == 0 -> both false/true-but-unflagged
 #pragma unroll
         for (int i = 0; i < ROWS / 32; ++i) {
-            bool ok = kok && ((flags >> i) & 1u);
-            if (((flags >> (8 + i)) & 1u) && seg0) ok = false;
-            if (((flags >> (16 + i)) & 1u) && seg2) ok = false;
+            bool ok = kok && ((valid >> i) & 1u);
+            if (((first >> i) & 1u) && seg0) ok = false;
+            if (((last >> i) & 1u) && seg2) ok = false;
             reg[i] = ok ? *reinterpret_cast<const float4*>(ptr[i] + k0) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
     }
@@ -87,46 +100,56 @@ __device__ __forceinline__ void store_kc(float* lds, const float4 (&reg)[ROWS / 
         *reinterpret_cast<float4*>(lds + (r0 + 32 * i) * KC_LD + c4) = reg[i];
 }
 
-// reduction-major operand: tile 32 (k) x COLS floats
+// reduction-major operand: tile 32 (k) x COLS floats = 8*COLS/256 float4 per thread, element
+// e = tid + 256*i -> k-row e / (COLS/4), column 4*(e % (COLS/4))   (COLS = 64, 128 or 320)
 template <int COLS>
 struct LoaderRM {
-    static constexpr int TPR = COLS / 4;     // threads per k-row
-    static constexpr int KPP = 256 / TPR;    // k-rows per pass
-    const float* colbase;                    // &base[c]
+    static constexpr int TPR = COLS / 4;     // float4 per k-row
+    static constexpr int NV = 8 * COLS / 256;
+    const float* base;
     int64_t ld;
-    int kr0;
-    bool cok, seg0, seg2;
-    __device__ __forceinline__ void init(const float* base, int64_t ld_, int col0, int ncols, int tid, int convE) {
-        const int c = col0 + (tid % TPR) * 4;
-        kr0 = tid / TPR;
-        cok = c < ncols;
-        colbase = base + (cok ? c : col0);
-        ld = ld_;
-        seg0 = c < convE;
-        seg2 = convE > 0 && c >= 2 * convE;
-    }
-    __device__ __forceinline__ void load(float4 (&reg)[COLS / 32], int k0, int K, int convT) const {
+    uint32_t off[NV];                        // byte offset of element i inside a k-tile: (kr*ld + column) * 4, column clamped
+    unsigned cvalid;                         // bit i: column in range
+    int col0, convE;
+    __device__ __forceinline__ void init(const float* base_, int64_t ld_, int col0_, int ncols, int tid, int convE_) {
+        base = base_; ld = ld_; col0 = col0_; convE = convE_;
+        cvalid = 0;
 #pragma unroll
-        for (int i = 0; i < COLS / 32; ++i) {
-            const int k = k0 + kr0 + KPP * i;
-            bool ok = cok && (k < K);
+        for (int i = 0; i < NV; ++i) {
+            const int e = tid + 256 * i, kr = e / TPR, c = col0 + (e - kr * TPR) * 4;
+            const bool ok = c < ncols;
+            if (ok) cvalid |= 1u << i;
+            off[i] = (uint32_t)(kr * (int)ld + (ok ? c : col0)) * 4u;
+        }
+    }
+    __device__ __forceinline__ void load_full(float4 (&reg)[NV], int k0, int) const {
+        const char* kb = reinterpret_cast<const char*>(base + (int64_t)k0 * ld);      // uniform
+#pragma unroll
+        for (int i = 0; i < NV; ++i) reg[i] = *reinterpret_cast<const float4*>(kb + off[i]);
+    }
+    __device__ __forceinline__ void load(float4 (&reg)[NV], int k0, int K, int convT, int tid) const {
+        const char* kb = reinterpret_cast<const char*>(base + (int64_t)k0 * ld);
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int e = tid + 256 * i, kr = e / TPR, c = col0 + (e - kr * TPR) * 4;
+            const int k = k0 + kr;
+            bool ok = ((cvalid >> i) & 1u) && (k < K);
             if (convT > 0) {
                 const int t = k % convT;
-                if ((t == 0 && seg0) || (t == convT - 1 && seg2)) ok = false;
+                if ((t == 0 && c < convE) || (t == convT - 1 && c >= 2 * convE)) ok = false;
             }
-            reg[i] = ok ? *reinterpret_cast<const float4*>(colbase + (int64_t)k * ld) : make_float4(0.f, 0.f, 0.f, 0.f);
+            reg[i] = ok ? *reinterpret_cast<const float4*>(kb + off[i]) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
     }
 };
 template <int COLS>
-__device__ __forceinline__ void store_rm(float* lds, const float4 (&reg)[COLS / 32], int tid) {
+__device__ __forceinline__ void store_rm(float* lds, const float4 (&reg)[8 * COLS / 256], int tid) {
     constexpr int TPR = COLS / 4;
-    constexpr int KPP = 256 / TPR;
-    const int c4 = (tid % TPR) * 4;
-    const int kr0 = tid / TPR;
 #pragma unroll
-    for (int i = 0; i < COLS / 32; ++i)
-        *reinterpret_cast<float4*>(lds + (kr0 + KPP * i) * RedMajor<COLS>::LD + c4) = reg[i];
+    for (int i = 0; i < 8 * COLS / 256; ++i) {
+        const int e = tid + 256 * i, kr = e / TPR, c4 = (e - kr * TPR) * 4;
+        *reinterpret_cast<float4*>(lds + kr * RedMajor<COLS>::LD + c4) = reg[i];
+    }
 }
 
 // epilogue math on a value whose aux operands are already in registers
@@ -164,52 +187,77 @@ __device__ __forceinline__ float epilogue(float v, int epi, int m, int n, const 
 }
 
 // write one wave's 64 x (32*NJ) accumulator block.  C/D map of the 32x32 MFMA:
-// col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5).  Aux operands of a 32x32 tile are
-// loaded as one batch BEFORE its stores (the compiler cannot prove C does not alias aux, so
-// interleaving them would serialise every element behind a full memory round trip).
-template <int EPI, int NJ, bool CHECK>
-__device__ __forceinline__ void store_block(const f32x16 (&acc)[2][NJ], float* __restrict__ C, int mw, int nw, int l31, int h,
+// col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5).  Addressing is wave-uniform base
+// (SGPR pair) + one 32-bit per-lane offset, so the 32*NJ stores need no per-lane 64-bit pointers.
+// Aux operands of a 32x32 tile are loaded as one batch BEFORE its stores (the compiler cannot prove
+// C does not alias aux, so interleaving them would serialise every element behind a round trip).
+__device__ __forceinline__ float& at_off(float* base, uint32_t off_bytes) {           // SGPR base + u32 VGPR offset
+    return *reinterpret_cast<float*>(reinterpret_cast<char*>(base) + off_bytes);
+}
+__device__ __forceinline__ float ld_off(const float* base, uint32_t off_bytes) {
+    return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(base) + off_bytes);
+}
+template <int EPI, int WM, int NJ, bool CHECK>
+__device__ __forceinline__ void store_block(const f32x16 (&acc)[WM][NJ], float* C, int mw, int nw, int l31, int h,
                                             bool use_bias, const GemmParams& p) {
+    const int64_t ldc = p.ldc, ldaux = p.ldaux, ldaux2 = p.ldaux2, ldout2 = p.ldout2;
+    const uint32_t vc = (uint32_t)(4 * h * (int)ldc + l31) * 4u;
+    const uint32_t va = (uint32_t)(4 * h * (int)ldaux + l31) * 4u;
+    const uint32_t va2 = (uint32_t)(4 * h * (int)ldaux2 + l31) * 4u;
+    const uint32_t vo2 = (uint32_t)(4 * h * (int)ldout2 + l31) * 4u;
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
-        const int n = nw + j * 32 + l31;
+        const int nb = nw + j * 32;                       // uniform
+        const int n = nb + l31;
         if (CHECK && n >= p.N) continue;
         const float bv = use_bias ? p.bias[n] : 0.f;
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int mb = mw + i * 32 + 4 * h;
+        for (int i = 0; i < WM; ++i) {
+            const int mb = mw + i * 32;                   // uniform
+            const int ml = mb + 4 * h;                    // first row of this lane
+            float* cb = C + mb * ldc + nb;
             float a[16], a2[16];
+            if (EpiTraits<EPI>::AUX) {
+                const float* ab = p.aux + mb * ldaux + nb;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int m = mb + (r & 3) + 8 * (r >> 2);
-                const bool ok = !CHECK || m < p.M;
-                a[r] = (EpiTraits<EPI>::AUX && ok) ? p.aux[(int64_t)m * p.ldaux + n] : 0.f;
-                a2[r] = (EpiTraits<EPI>::AUX2 && ok) ? p.aux2[(int64_t)m * p.ldaux2 + n] : 0.f;
+                for (int r = 0; r < 16; ++r) {
+                    const int ro = (r & 3) + 8 * (r >> 2);
+                    a[r] = (!CHECK || ml + ro < p.M) ? ld_off(ab + ro * ldaux, va) : 0.f;
+                }
             }
+            if (EpiTraits<EPI>::AUX2) {
+                const float* ab = p.aux2 + mb * ldaux2 + nb;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int ro = (r & 3) + 8 * (r >> 2);
+                    a2[r] = (!CHECK || ml + ro < p.M) ? ld_off(ab + ro * ldaux2, va2) : 0.f;
+                }
+            }
+            float* ob = (EPI == EPI_GELU && p.out2) ? p.out2 + mb * ldout2 + nb : nullptr;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int m = mb + (r & 3) + 8 * (r >> 2);
-                if (CHECK && m >= p.M) continue;
+                const int ro = (r & 3) + 8 * (r >> 2);
+                if (CHECK && ml + ro >= p.M) continue;
                 const float v = acc[i][j][r] + bv;
-                if (EPI == EPI_GELU && p.out2) p.out2[(int64_t)m * p.ldout2 + n] = v;
-                C[(int64_t)m * p.ldc + n] = epi_math<EPI>(v, a[r], a2[r]);
+                if (EPI == EPI_GELU && ob) at_off(ob + ro * ldout2, vo2) = v;
+                at_off(cb + ro * ldc, vc) = epi_math<EPI>(v, EpiTraits<EPI>::AUX ? a[r] : 0.f, EpiTraits<EPI>::AUX2 ? a2[r] : 0.f);
             }
         }
     }
 }
 
-template <bool A_KC, bool B_KC, int NJ>
-__global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const GemmParams p) {
-    constexpr int BN = 64 * NJ;
+template <bool A_KC, bool B_KC, int WM, int NJ>
+__global__ __launch_bounds__(256, (WM * NJ <= 2) ? 4 : (WM * NJ <= 4 ? 3 : 2)) void gemm_f32_kernel(const GemmParams p) {
+    constexpr int BM = 64 * WM, BN = 64 * NJ;
     constexpr int A_ELEMS = A_KC ? BM * KC_LD : BK * RedMajor<BM>::LD;
-    constexpr int B_ELEMS = B_KC ? BN * KC_LD : BK * RedMajor<BN>::LD;
+    constexpr int NVA = 8 * BM / 256, NVB = 8 * BN / 256;     // float4 per thread per k-tile
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* As = smem;                       // [2][A_ELEMS]
-    float* Bs = smem + 2 * A_ELEMS;         // [2][B_ELEMS]
+    float* As = smem;                       // one buffer each (see header)
+    float* Bs = smem + A_ELEMS;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    const int wid = tid >> 6;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform: keeps tile bases in SGPRs
     const int wr = wid >> 1, wc = wid & 1;
     const int l31 = lane & 31, h = lane >> 5;
 
@@ -234,114 +282,145 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const GemmParams p) {
     const int kt_begin = ks * kt_per;
     const int kt_end = min(kt_total, kt_begin + kt_per);
 
-    f32x16 acc[2][NJ];
+    f32x16 acc[WM][NJ];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < WM; ++i)
 #pragma unroll
         for (int j = 0; j < NJ; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    float4 ra[BM / 32];
-    float4 rb[BN / 32];
+    float4 ra[NVA];
+    float4 rb[NVB];
     const int convA = (p.conv_on == 1) ? p.conv_T : 0;
     const int convB = (p.conv_on == 2) ? p.conv_T : 0;
     LoaderKC<BM> lkA; LoaderRM<BM> lrA; LoaderKC<BN> lkB; LoaderRM<BN> lrB;
     if (A_KC) lkA.init(p.A, p.lda, m0, p.M, tid, convA); else lrA.init(p.A, p.lda, m0, p.M, tid, 0);
     if (B_KC) lkB.init(p.B, p.ldb, n0, p.N, tid, 0);     else lrB.init(p.B, p.ldb, n0, p.N, tid, convB ? p.conv_E : 0);
 
-    auto gload = [&](int kt) {
+    // Full k-tiles of a non-conv GEMM load unconditionally: rows/columns past the edge read a clamped
+    // (valid) address and only ever reach output elements that are not stored.
+    const bool plain = p.conv_on == 0;      // uniform
+    auto gloadA = [&](int kt, bool fullk) {
         const int k0 = kt * BK;
-        if (A_KC) lkA.load(ra, k0, p.K, convA ? p.conv_E : 0); else lrA.load(ra, k0, p.K, 0);
-        if (B_KC) lkB.load(rb, k0, p.K, 0);                    else lrB.load(rb, k0, p.K, convB);
+        if (fullk && plain) { if (A_KC) lkA.load_full(ra, k0); else lrA.load_full(ra, k0, tid); }
+        else { if (A_KC) lkA.load(ra, k0, p.K, convA ? p.conv_E : 0); else lrA.load(ra, k0, p.K, 0, tid); }
     };
-    auto lstore = [&](int buf) {
-        if (A_KC) store_kc<BM>(As + buf * A_ELEMS, ra, tid);
-        else      store_rm<BM>(As + buf * A_ELEMS, ra, tid);
-        if (B_KC) store_kc<BN>(Bs + buf * B_ELEMS, rb, tid);
-        else      store_rm<BN>(Bs + buf * B_ELEMS, rb, tid);
+    auto gloadB = [&](int kt, bool fullk) {
+        const int k0 = kt * BK;
+        if (fullk && plain) { if (B_KC) lkB.load_full(rb, k0); else lrB.load_full(rb, k0, tid); }
+        else { if (B_KC) lkB.load(rb, k0, p.K, 0); else lrB.load(rb, k0, p.K, convB, tid); }
+    };
+    auto lstore = [&]() {
+        if (A_KC) store_kc<BM>(As, ra, tid); else store_rm<BM>(As, ra, tid);
+        if (B_KC) store_kc<BN>(Bs, rb, tid); else store_rm<BN>(Bs, rb, tid);
     };
 
+    // LDS -> register fragments of one k-quad (8 k) and the MFMAs that consume them.  The fragments
+    // are software-pipelined by hand (reads of quad q+1 are issued before the MFMAs of quad q): the
+    // compiler does not overlap them on its own and a wave then idles for the LDS latency 2x per tile.
+    struct Frags { float a[WM][4]; float b[NJ][4]; };
+    auto fload = [&](Frags& f, int kq) {
+        const int kb = kq * 8 + 4 * h;
+#pragma unroll
+        for (int i = 0; i < WM; ++i) {
+            const int row = wr * (32 * WM) + i * 32 + l31;
+            if (A_KC) {
+                const float4 v = *reinterpret_cast<const float4*>(As + row * KC_LD + kb);
+                f.a[i][0] = v.x; f.a[i][1] = v.y; f.a[i][2] = v.z; f.a[i][3] = v.w;
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) f.a[i][e] = As[(kb + e) * RedMajor<BM>::LD + row];
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            const int col = wc * (BN / 2) + j * 32 + l31;
+            if (B_KC) {
+                const float4 v = *reinterpret_cast<const float4*>(Bs + col * KC_LD + kb);
+                f.b[j][0] = v.x; f.b[j][1] = v.y; f.b[j][2] = v.z; f.b[j][3] = v.w;
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) f.b[j][e] = Bs[(kb + e) * RedMajor<BN>::LD + col];
+            }
+        }
+    };
+    auto fmma = [&](const Frags& f) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int i = 0; i < WM; ++i)
+#pragma unroll
+                for (int j = 0; j < NJ; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a[i][e], f.b[j][e], acc[i][j], 0, 0, 0);
+    };
+
+    // tiles [kt_begin, kt_full) are complete (4 quads); at most one ragged tile follows
+    const int kt_full = min(kt_end, p.K / BK);
     if (kt_begin < kt_end) {
-        gload(kt_begin);
-        lstore(0);
+        gloadA(kt_begin, false);
+        gloadB(kt_begin, false);
+        lstore();
     }
     __syncthreads();
 
-    int cur = 0;
-    for (int kt = kt_begin; kt < kt_end; ++kt) {
+    for (int kt = kt_begin; kt < kt_full; ++kt) {
         const bool more = kt + 1 < kt_end;
-        if (more) gload(kt + 1);
-
-        const float* Ab = As + cur * A_ELEMS;
-        const float* Bb = Bs + cur * B_ELEMS;
-        const int krem = min(BK, p.K - kt * BK);
-        const int nkq = (krem + 7) >> 3;
-        auto kstep = [&](int kq) {
-            float a[2][4], b[NJ][4];
-            const int kb = kq * 8 + 4 * h;
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                const int row = wr * 64 + i * 32 + l31;
-                if (A_KC) {
-                    const float4 v = *reinterpret_cast<const float4*>(Ab + row * KC_LD + kb);
-                    a[i][0] = v.x; a[i][1] = v.y; a[i][2] = v.z; a[i][3] = v.w;
-                } else {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) a[i][e] = Ab[(kb + e) * RedMajor<BM>::LD + row];
-                }
-            }
-#pragma unroll
-            for (int j = 0; j < NJ; ++j) {
-                const int col = wc * (BN / 2) + j * 32 + l31;
-                if (B_KC) {
-                    const float4 v = *reinterpret_cast<const float4*>(Bb + col * KC_LD + kb);
-                    b[j][0] = v.x; b[j][1] = v.y; b[j][2] = v.z; b[j][3] = v.w;
-                } else {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) b[j][e] = Bb[(kb + e) * RedMajor<BN>::LD + col];
-                }
-            }
-#pragma unroll
-            for (int e = 0; e < 4; ++e)
-#pragma unroll
-                for (int i = 0; i < 2; ++i)
-#pragma unroll
-                    for (int j = 0; j < NJ; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][e], b[j][e], acc[i][j], 0, 0, 0);
-        };
-        if (nkq == BK / 8) {
-#pragma unroll
-            for (int kq = 0; kq < BK / 8; ++kq) kstep(kq);
-        } else {
-            for (int kq = 0; kq < nkq; ++kq) kstep(kq);
-        }
-        if (more) lstore(cur ^ 1);
+        const bool nfull = kt + 1 < kt_full;
+        Frags f0, f1;
+        fload(f0, 0);
+        fload(f1, 1);
+        __builtin_amdgcn_sched_barrier(0);
+        if (more) gloadA(kt + 1, nfull);     // issued behind the first LDS reads: the MFMAs start at once
+        fmma(f0);
+        __builtin_amdgcn_sched_barrier(0);
+        fload(f0, 2);
+        if (more) gloadB(kt + 1, nfull);
+        __builtin_amdgcn_sched_barrier(0);
+        fmma(f1);
+        __builtin_amdgcn_sched_barrier(0);
+        fload(f1, 3);
+        __builtin_amdgcn_sched_barrier(0);
+        fmma(f0);
+        fmma(f1);
+        __syncthreads();                     // everyone is done reading the single buffer
+        if (more) lstore();
         __syncthreads();
-        cur ^= 1;
+    }
+    if (kt_full < kt_end) {                  // ragged last tile: only the quads that hold k < K (the loader zero-fills)
+        const int nkq = (p.K - kt_full * BK + 7) >> 3;
+        for (int kq = 0; kq < nkq; ++kq) {
+            Frags f;
+            fload(f, kq);
+            fmma(f);
+        }
     }
 
     // ---- epilogue (one switch per wave, straight-line stores inside)
     const bool partial = p.ksplit > 1;
     float* Cout = partial ? p.C + (int64_t)ks * p.split_stride : p.C;
-    const int mw = m0 + wr * 64, nw = n0 + wc * (BN / 2);
-    const bool full = (mw + 64 <= p.M) && (nw + BN / 2 <= p.N);
+    const int mw = m0 + wr * (32 * WM), nw = n0 + wc * (BN / 2);
+    const bool full = (mw + 32 * WM <= p.M) && (nw + BN / 2 <= p.N);
     const bool ub = !partial && p.bias != nullptr;
     const int epi = partial ? EPI_NONE : p.epi;
 #define NR_STORE(E)                                                                        \
     do {                                                                                   \
-        if (full) store_block<E, NJ, false>(acc, Cout, mw, nw, l31, h, ub, p);             \
-        else      store_block<E, NJ, true>(acc, Cout, mw, nw, l31, h, ub, p);              \
+        if (full) store_block<E, WM, NJ, false>(acc, Cout, mw, nw, l31, h, ub, p);         \
+        else      store_block<E, WM, NJ, true>(acc, Cout, mw, nw, l31, h, ub, p);          \
     } while (0)
-    switch (epi) {
-        case EPI_NONE: NR_STORE(EPI_NONE); break;
-        case EPI_RELU: NR_STORE(EPI_RELU); break;
-        case EPI_GELU: NR_STORE(EPI_GELU); break;
-        case EPI_TANH: NR_STORE(EPI_TANH); break;
-        case EPI_ADD_AUX: NR_STORE(EPI_ADD_AUX); break;
-        case EPI_MUL_GELU_GRAD: NR_STORE(EPI_MUL_GELU_GRAD); break;
-        case EPI_ADD_AUX_RELUMASK: NR_STORE(EPI_ADD_AUX_RELUMASK); break;
-        case EPI_RELUMASK: NR_STORE(EPI_RELUMASK); break;
+    if (WM > 2) {                            // the tall tile only ever writes split-K slabs / plain dW
+        NR_STORE(EPI_NONE);
+    } else {
+        switch (epi) {
+            case EPI_NONE: NR_STORE(EPI_NONE); break;
+            case EPI_RELU: NR_STORE(EPI_RELU); break;
+            case EPI_GELU: NR_STORE(EPI_GELU); break;
+            case EPI_TANH: NR_STORE(EPI_TANH); break;
+            case EPI_ADD_AUX: NR_STORE(EPI_ADD_AUX); break;
+            case EPI_MUL_GELU_GRAD: NR_STORE(EPI_MUL_GELU_GRAD); break;
+            case EPI_ADD_AUX_RELUMASK: NR_STORE(EPI_ADD_AUX_RELUMASK); break;
+            case EPI_RELUMASK: NR_STORE(EPI_RELUMASK); break;
+        }
     }
 #undef NR_STORE
 }
@@ -382,22 +461,19 @@ __global__ __launch_bounds__(256) void gemm_naive_kernel(const GemmParams p) {
     }
 }
 
-template <bool A_KC, bool B_KC, int NJ>
+template <bool A_KC, bool B_KC, int WM, int NJ>
 static int launch_tiled(const GemmParams& p, hipStream_t s) {
-    constexpr int BN = 64 * NJ;
+    constexpr int BM = 64 * WM, BN = 64 * NJ;
     constexpr int A_ELEMS = A_KC ? BM * KC_LD : BK * RedMajor<BM>::LD;
     constexpr int B_ELEMS = B_KC ? BN * KC_LD : BK * RedMajor<BN>::LD;
-    const size_t lds = 2 * (A_ELEMS + B_ELEMS) * sizeof(float);
+    const size_t lds = (A_ELEMS + B_ELEMS) * sizeof(float);
     const int tiles = cdiv(p.M, BM) * cdiv(p.N, BN);
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f32_kernel<A_KC, B_KC, NJ>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_set = true;
-    }
-    hipLaunchKernelGGL((gemm_f32_kernel<A_KC, B_KC, NJ>), dim3(tiles * p.ksplit), dim3(256), lds, s, p);
+    hipLaunchKernelGGL((gemm_f32_kernel<A_KC, B_KC, WM, NJ>), dim3(tiles * p.ksplit), dim3(256), lds, s, p);
     return check_launch("gemm_f32");
 }
+
+// dW GEMMs (both operands reduction-major, split-K): the tall 320-row tile when it pads M less than 128-row tiles
+static bool tall_tile(int M) { return cdiv(M, 320) * 320 < cdiv(M, 128) * 128; }
 
 size_t gemm_workspace_bytes(int M, int N, int ksplit) {
     return ksplit > 1 ? (size_t)ksplit * M * N * sizeof(float) : 0;
@@ -405,7 +481,7 @@ size_t gemm_workspace_bytes(int M, int N, int ksplit) {
 
 int choose_ksplit(int M, int N, int K) {
     // fill ~2 waves of 256 CUs when the output grid alone cannot (dW GEMMs: tiny MxN, huge K)
-    const int tiles = cdiv(M, BM) * cdiv(N, 64);
+    const int tiles = cdiv(M, tall_tile(M) ? 320 : 128) * cdiv(N, 64);
     const int kt = cdiv(K, BK);
     if (tiles >= 256 || kt < 16) return 1;
     int ks = (512 + tiles - 1) / tiles;
@@ -448,9 +524,12 @@ int gemm_f32(GemmParams p, bool a_kc, bool b_kc, float* workspace, size_t ws_byt
     // BN=128 only when it wastes no more columns than BN=64
     const bool wide = (cdiv(p.N, 128) * 128 == cdiv(p.N, 64) * 64) && p.N >= 128;
     int rc;
-    if (a_kc && b_kc)        rc = wide ? launch_tiled<true, true, 2>(q, s) : launch_tiled<true, true, 1>(q, s);
-    else if (a_kc && !b_kc)  rc = wide ? launch_tiled<true, false, 2>(q, s) : launch_tiled<true, false, 1>(q, s);
-    else if (!a_kc && !b_kc) rc = wide ? launch_tiled<false, false, 2>(q, s) : launch_tiled<false, false, 1>(q, s);
+    if (a_kc && b_kc)        rc = wide ? launch_tiled<true, true, 2, 2>(q, s) : launch_tiled<true, true, 2, 1>(q, s);
+    else if (a_kc && !b_kc)  rc = wide ? launch_tiled<true, false, 2, 2>(q, s) : launch_tiled<true, false, 2, 1>(q, s);
+    else if (!a_kc && !b_kc) {
+        if (!p.conv_on && !wide && (p.epi == EPI_NONE || p.ksplit > 1) && tall_tile(p.M)) rc = launch_tiled<false, false, 5, 1>(q, s);
+        else rc = wide ? launch_tiled<false, false, 2, 2>(q, s) : launch_tiled<false, false, 2, 1>(q, s);
+    }
     else { set_error("gemm: layout (A red-major, B k-contig) not built"); return NR_ERR_UNSUPPORTED; }
     if (rc != NR_OK) return rc;
     if (p.ksplit > 1) {

@@ -24,7 +24,8 @@ for name, K, N in shapes:
     res = []
     for tag, fn in (("fwd", lambda: ops.linear_fwd(x, w, b)), ("fwd+gelu", lambda: ops.linear_fwd(x, w, b, "gelu", z)),
                     ("dX", lambda: ops.linear_bwd_input(dy, w)), ("dX+aux", lambda: ops.linear_bwd_input(dy, w, 1, aux)),
-                    ("dX*gelu'", lambda: ops.linear_bwd_input(dy, w, 2, aux)), ("dW", lambda: ops.linear_bwd_weight(dy, x))):
+                    ("dX*gelu'", lambda: ops.linear_bwd_input(dy, w, 2, aux)), ("dW", lambda: ops.linear_bwd_weight(dy, x)),
+                    ("vendor_fwd", lambda: torch.addmm(b, x, w.t())), ("vendor_dW", lambda: dy.t() @ x)):
         ms = timeit(fn)
         res.append(f"{tag} {ms*1e3:7.1f}us {fl/ms/1e9:6.1f}TF")
     print(f"{name:9s} R={R} K={K:4d} N={N:4d} | " + " | ".join(res), flush=True)
