@@ -175,7 +175,7 @@ def main():
         step(i)
     torch.cuda.synchronize()
     fam = {}
-    for name, idx in (("gemm", 0), ("gather", 1), ("attention", 2), ("layernorm", 3), ("pool", 4), ("score", 5), ("misc", 6)):
+    for name, idx in (("gemm", 0), ("gather", 1), ("attention", 2), ("layernorm", 3), ("pool", 4), ("score", 5), ("misc", 6), ("scatter_add", 7)):
         ms, n, work = ops.prof_read(idx)
         fam[name] = dict(ms_per_step=round(ms / args.steps, 4), launches_per_step=n / args.steps, work_per_step=work / args.steps)
     ops.prof_enable(False)
@@ -187,7 +187,7 @@ def main():
                 "launches_per_step": gm["launches_per_step"], "avg_launch_ms": round(gm["ms_per_step"] / max(gm["launches_per_step"], 1), 5),
                 "flops_per_step": gm["work_per_step"]}
     hbm = {}
-    for name in ("gather", "layernorm", "pool", "score"):
+    for name in ("gather", "layernorm", "pool", "score", "scatter_add"):
         f = fam[name]
         if f["ms_per_step"] > 0:
             gbs = f["work_per_step"] / (f["ms_per_step"] * 1e-3) / 1e9

@@ -43,7 +43,7 @@ const char* nr_last_error(void);
  * When enabled, every launch of a kernel family is bracketed by HIP events on its stream.
  * nr_prof_read synchronises those events, returns the family's summed device time (ms), launch
  * count and summed algorithmic work (flops for family 0, bytes otherwise) and clears them. */
-enum { NR_FAM_GEMM = 0, NR_FAM_GATHER = 1, NR_FAM_ATTN = 2, NR_FAM_LN = 3, NR_FAM_POOL = 4, NR_FAM_SCORE = 5, NR_FAM_MISC = 6, NR_FAM_COUNT = 7 };
+enum { NR_FAM_GEMM = 0, NR_FAM_GATHER = 1, NR_FAM_ATTN = 2, NR_FAM_LN = 3, NR_FAM_POOL = 4, NR_FAM_SCORE = 5, NR_FAM_MISC = 6, NR_FAM_SCATTER = 7, NR_FAM_COUNT = 8 };
 int nr_prof_enable(int on);
 int nr_prof_read(int family, double* ms, int64_t* launches, double* work);
 
@@ -162,6 +162,11 @@ int nr_tfm_layer_bwd_f32(const float* dy, const float* x, const int64_t* mask, i
  * torch defaults (betas 0.9/0.999, eps 1e-8, no weight decay, no amsgrad); step counts from 1.
  * Hyper-parameters are doubles: torch forms 1-beta, lr/(1-beta1^t), sqrt(1-beta2^t) in double before rounding to fp32. */
 int nr_adam_step_f32(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, double lr, double beta1, double beta2, double eps, int64_t step, void* stream);
+/* The same update for `count` tensors that share one step number, in one launch per 48 tensors (reference
+ * BaseModel.py:46 builds ONE Adam over self.parameters(); manager.py:392 steps it once per batch).  The five
+ * tables are HOST arrays of device pointers / element counts; they are copied into the kernel arguments. */
+int nr_adam_multi_f32(int count, float* const* params, const float* const* grads, float* const* exp_avg, float* const* exp_avg_sq,
+                      const int64_t* numel, double lr, double beta1, double beta2, double eps, int64_t step, void* stream);
 
 #ifdef __cplusplus
 }

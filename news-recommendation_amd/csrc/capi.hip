@@ -345,6 +345,17 @@ int nr_adam_step_f32(float* param, const float* grad, float* exp_avg, float* exp
     return adam_f32(param, grad, exp_avg, exp_avg_sq, n, lr, beta1, beta2, eps, step, S(stream));
 }
 
+int nr_adam_multi_f32(int count, float* const* params, const float* const* grads, float* const* exp_avg, float* const* exp_avg_sq,
+                      const int64_t* numel, double lr, double beta1, double beta2, double eps, int64_t step, void* stream) {
+    NR_CHECK_ARG(count >= 0 && step >= 1, "adam_multi: bad sizes");
+    NR_CHECK_ARG(count == 0 || (params && grads && exp_avg && exp_avg_sq && numel), "adam_multi: null table");
+    for (int i = 0; i < count; ++i) {
+        NR_CHECK_ARG(numel[i] >= 0, "adam_multi: tensor %d has negative size", i);
+        NR_CHECK_ARG(numel[i] == 0 || (params[i] && grads[i] && exp_avg[i] && exp_avg_sq[i]), "adam_multi: tensor %d has a null pointer", i);
+    }
+    return adam_multi_f32(count, params, grads, exp_avg, exp_avg_sq, numel, lr, beta1, beta2, eps, step, S(stream));
+}
+
 // ------------------------------------------------------------------------------------ TFM layer
 static bool contiguous3(const float* a, const float* b, const float* c, size_t n) { return b == a + n && c == b + n; }
 

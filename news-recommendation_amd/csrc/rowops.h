@@ -29,5 +29,8 @@ int relu_bwd_f32(const float* dy, const float* y, float* o, int64_t n, hipStream
 int mean_f32(const float* v, int n, float* out, hipStream_t s);
 int adam_f32(float* p, const float* g, float* m, float* v, int64_t n, double lr, double b1, double b2, double eps, int64_t step,
              hipStream_t s);
+constexpr int ADAM_MAX_TENSORS = 48;   // tensors per launch (the table travels in the kernel arguments)
+int adam_multi_f32(int count, float* const* p, const float* const* g, float* const* m, float* const* v, const int64_t* n,
+                   double lr, double b1, double b2, double eps, int64_t step, hipStream_t s);
 
 }  // namespace nr

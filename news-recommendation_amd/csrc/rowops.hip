@@ -88,7 +88,7 @@ __global__ __launch_bounds__(256) void scatter_add_rows_kernel(const float* __re
 int scatter_add_rows(const float* grad_rows, const int64_t* ids, int64_t n, int E, int64_t V, int64_t padding_idx,
                      float* grad_table, hipStream_t s) {
     if (n == 0) return NR_OK;
-    ProfScope prof(FAM_GATHER, s, 2.0 * n * E * 4);
+    ProfScope prof(FAM_SCATTER, s, 2.0 * n * E * 4);
     const int grid = (int)std::min<int64_t>(cdiv(n, WAVES_PER_BLOCK), 8192);
     hipLaunchKernelGGL(scatter_add_rows_kernel, dim3(grid), dim3(256), 0, s, grad_rows, ids, grad_table, n, E, V, padding_idx);
     return check_launch("scatter_add_rows");
@@ -500,6 +500,87 @@ int adam_f32(float* p, const float* g, float* m, float* v, int64_t n, double lr,
     hipLaunchKernelGGL(adam_kernel, dim3((int)std::min<int64_t>(cdiv(n, 256), 8192)), dim3(256), 0, s, p, g, m, v, n, omb1, (float)b2,
                        omb2, (float)eps, step_size, bc2_sqrt);
     return check_launch("adam");
+}
+
+// All parameters of a model in ONE launch (39 per-tensor launches cost 4x the bandwidth time of the update itself).
+// The tensor table travels by value in the kernel arguments; block b updates one 4096-element chunk of the tensor
+// whose block range contains b.
+struct AdamTable {
+    float* p[ADAM_MAX_TENSORS];
+    const float* g[ADAM_MAX_TENSORS];
+    float* m[ADAM_MAX_TENSORS];
+    float* v[ADAM_MAX_TENSORS];
+    int64_t n[ADAM_MAX_TENSORS];
+    int blk0[ADAM_MAX_TENSORS + 1];
+    int count;
+};
+constexpr int ADAM_CHUNK = 4096;
+
+__global__ __launch_bounds__(256) void adam_multi_kernel(const AdamTable t, float omb1, float b2, float omb2, float eps,
+                                                         float step_size, float bc2_sqrt) {
+    int lo = 0, hi = t.count - 1;                  // last tensor with blk0 <= blockIdx.x
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (t.blk0[mid] <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
+    }
+    float* __restrict__ p = t.p[lo];
+    const float* __restrict__ g = t.g[lo];
+    float* __restrict__ m = t.m[lo];
+    float* __restrict__ v = t.v[lo];
+    const int64_t n = t.n[lo];
+    const int64_t base = (int64_t)(blockIdx.x - t.blk0[lo]) * ADAM_CHUNK;
+    const int64_t end = min(n, base + ADAM_CHUNK);
+    const bool vec = ((reinterpret_cast<uintptr_t>(p) | reinterpret_cast<uintptr_t>(g) | reinterpret_cast<uintptr_t>(m) |
+                       reinterpret_cast<uintptr_t>(v)) & 15) == 0;
+    auto upd = [&](float& pi, float gi, float& mi_, float& vi_) {
+        const float mi = mi_ + omb1 * (gi - mi_);
+        const float vi = vi_ * b2 + omb2 * gi * gi;
+        const float denom = sqrtf(vi) / bc2_sqrt + eps;
+        pi = pi - step_size * (mi / denom);
+        mi_ = mi; vi_ = vi;
+    };
+    if (vec && base + ADAM_CHUNK <= n) {
+#pragma unroll
+        for (int u = 0; u < ADAM_CHUNK / 1024; ++u) {
+            const int64_t i = base + (u * 256 + threadIdx.x) * 4;
+            float4 pp = *reinterpret_cast<float4*>(p + i), mm = *reinterpret_cast<float4*>(m + i), vv = *reinterpret_cast<float4*>(v + i);
+            const float4 gg = *reinterpret_cast<const float4*>(g + i);
+            upd(pp.x, gg.x, mm.x, vv.x); upd(pp.y, gg.y, mm.y, vv.y); upd(pp.z, gg.z, mm.z, vv.z); upd(pp.w, gg.w, mm.w, vv.w);
+            *reinterpret_cast<float4*>(p + i) = pp; *reinterpret_cast<float4*>(m + i) = mm; *reinterpret_cast<float4*>(v + i) = vv;
+        }
+    } else {
+        for (int64_t i = base + threadIdx.x; i < end; i += 256) upd(p[i], g[i], m[i], v[i]);
+    }
+}
+
+int adam_multi_f32(int count, float* const* p, const float* const* g, float* const* m, float* const* v, const int64_t* n,
+                   double lr, double b1, double b2, double eps, int64_t step, hipStream_t s) {
+    const double bc1 = 1.0 - pow(b1, (double)step);
+    const double bc2 = 1.0 - pow(b2, (double)step);
+    const float step_size = (float)(lr / bc1);
+    const float bc2_sqrt = (float)sqrt(bc2);
+    const float omb1 = (float)(1.0 - b1), omb2 = (float)(1.0 - b2);
+    int i = 0;
+    while (i < count) {
+        AdamTable t;
+        t.count = 0;
+        int blocks = 0;
+        double elems = 0;
+        for (; i < count && t.count < ADAM_MAX_TENSORS; ++i) {
+            if (n[i] == 0) continue;
+            const int c = t.count++;
+            t.p[c] = p[i]; t.g[c] = g[i]; t.m[c] = m[i]; t.v[c] = v[i]; t.n[c] = n[i];
+            t.blk0[c] = blocks;
+            blocks += cdiv(n[i], ADAM_CHUNK);
+            elems += (double)n[i];
+        }
+        if (t.count == 0) continue;
+        t.blk0[t.count] = blocks;
+        ProfScope prof(FAM_MISC, s, elems * 4 * 7);
+        hipLaunchKernelGGL(adam_multi_kernel, dim3(blocks), dim3(256), 0, s, t, omb1, (float)b2, omb2, (float)eps, step_size, bc2_sqrt);
+        if (int rc = check_launch("adam_multi")) return rc;
+    }
+    return NR_OK;
 }
 
 }  // namespace nr

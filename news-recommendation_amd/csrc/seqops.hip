@@ -63,6 +63,12 @@ __device__ __forceinline__ void axpy_rows(float4 (&o)[IT], float a, const float4
 
 // ------------------------------------------------------------------ pooling forward
 // out[n] = softmax_s( q.key[n,s]/sqrt(D) + (1-mask[n,s])*(-1e5) ) . value[n,s]
+// One 256-thread block per sequence: wave w owns positions s = w, w+4, ... and keeps PB of its rows in
+// flight at a time (a sequence per wave left ~7 waves per CU on the NRMS shape: latency-, not HBM-bound).
+// Scores meet in LDS; every wave then forms the softmax redundantly (one score per lane) and
+// accumulates prob * value over its own rows; the four partial rows are summed through LDS.
+constexpr int PB = 4;                  // rows in flight per wave
+
 template <int IT>
 __global__ __launch_bounds__(256) void pool_fwd_kernel(const float* __restrict__ key, const float* __restrict__ value,
                                                        const float* __restrict__ table, const int64_t* __restrict__ idx,
@@ -70,34 +76,65 @@ __global__ __launch_bounds__(256) void pool_fwd_kernel(const float* __restrict__
                                                        const float* __restrict__ query, const int64_t* __restrict__ mask,
                                                        float* __restrict__ out, float* __restrict__ prob, int64_t nseq,
                                                        int S, int D) {
-    const int lane = threadIdx.x & 63;
-    const int64_t n = (int64_t)blockIdx.x * WPB + (threadIdx.x >> 6);
-    if (n >= nseq) return;
+    __shared__ float sc[64];
+    __shared__ __attribute__((aligned(16))) float part[WPB][IT * 256];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int64_t n = blockIdx.x;
     float4 q[IT];
     load_row<IT>(q, query, D, lane);
     const float sq = sqrtf((float)D);
-    float myscore = -INFINITY;
-    for (int s = 0; s < S; ++s) {
-        float4 k[IT];
-        load_row<IT>(k, row_ptr(key, table, idx, nrows, n, S, s, D), D, lane);
-        float x = dot_rows<IT>(q, k) / sq;
-        if (mask) x += mask[n * S + s] ? 0.f : MASK_FILL;
-        if (lane == s) myscore = x;
+    for (int s0 = w; s0 < S; s0 += WPB * PB) {
+        float4 k[PB][IT];
+#pragma unroll
+        for (int b = 0; b < PB; ++b) {
+            const int s = s0 + b * WPB;
+            if (s < S) load_row<IT>(k[b], row_ptr(key, table, idx, nrows, n, S, s, D), D, lane);
+        }
+#pragma unroll
+        for (int b = 0; b < PB; ++b) {
+            const int s = s0 + b * WPB;
+            if (s < S) {
+                float x = dot_rows<IT>(q, k[b]) / sq;
+                if (mask) x += mask[n * S + s] ? 0.f : MASK_FILL;
+                if (lane == 0) sc[s] = x;
+            }
+        }
     }
+    __syncthreads();
+    const float myscore = lane < S ? sc[lane] : -INFINITY;
     const float m = wave_max(myscore);
     const float e = lane < S ? expf(myscore - m) : 0.f;
     const float sum = wave_sum(e);
     const float p = e / sum;
-    if (prob && lane < S) prob[n * S + lane] = p;
+    if (prob && w == 0 && lane < S) prob[n * S + lane] = p;
     float4 acc[IT];
 #pragma unroll
     for (int it = 0; it < IT; ++it) acc[it] = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int s = 0; s < S; ++s) {
-        float4 v[IT];
-        load_row<IT>(v, row_ptr(value, table, idx, nrows, n, S, s, D), D, lane);
-        axpy_rows<IT>(acc, __shfl(p, s, 64), v);
+    for (int s0 = w; s0 < S; s0 += WPB * PB) {
+        float4 v[PB][IT];
+#pragma unroll
+        for (int b = 0; b < PB; ++b) {
+            const int s = s0 + b * WPB;
+            if (s < S) load_row<IT>(v[b], row_ptr(value, table, idx, nrows, n, S, s, D), D, lane);
+        }
+#pragma unroll
+        for (int b = 0; b < PB; ++b) {
+            const int s = s0 + b * WPB;
+            if (s < S) axpy_rows<IT>(acc, __shfl(p, s, 64), v[b]);
+        }
     }
-    store_row<IT>(out + n * (int64_t)D, acc, D, lane);
+    // fixed-order cross-wave sum (deterministic): wave w writes its partial, the block adds 0+1+2+3
+#pragma unroll
+    for (int it = 0; it < IT; ++it) *reinterpret_cast<float4*>(&part[w][(it * 64 + lane) * 4]) = acc[it];
+    __syncthreads();
+    for (int c = threadIdx.x * 4; c < D; c += 1024) {
+        const float4 a0 = *reinterpret_cast<const float4*>(&part[0][c]), a1 = *reinterpret_cast<const float4*>(&part[1][c]);
+        const float4 a2 = *reinterpret_cast<const float4*>(&part[2][c]), a3 = *reinterpret_cast<const float4*>(&part[3][c]);
+        float4 r;
+        r.x = ((a0.x + a1.x) + a2.x) + a3.x; r.y = ((a0.y + a1.y) + a2.y) + a3.y;
+        r.z = ((a0.z + a1.z) + a2.z) + a3.z; r.w = ((a0.w + a1.w) + a2.w) + a3.w;
+        *reinterpret_cast<float4*>(out + n * (int64_t)D + c) = r;
+    }
 }
 
 // ------------------------------------------------------------------ pooling backward
@@ -107,52 +144,85 @@ __global__ __launch_bounds__(256) void pool_fwd_kernel(const float* __restrict__
 //   dkey_s   = dscore_s q          -> through tanh: dz_s = dkey_s * (1 - key_s^2)   (tanh_key != 0)
 //   dq_part[n] = sum_s dscore_s key_s
 // key_is_value (AttnUserEncoder: key = value = x, no projection): dvalue_s += dkey_s, dkeypre unused.
+// Same block-per-sequence split as the forward kernel.
 template <int IT>
 __global__ __launch_bounds__(256) void pool_bwd_kernel(const float* __restrict__ key, const float* __restrict__ value,
                                                        const float* __restrict__ query, const float* __restrict__ prob,
                                                        const float* __restrict__ dout, float* __restrict__ dkeypre,
                                                        float* __restrict__ dvalue, float* __restrict__ dq_part,
                                                        int64_t nseq, int S, int D, int tanh_key, int key_is_value) {
-    const int lane = threadIdx.x & 63;
-    const int64_t n = (int64_t)blockIdx.x * WPB + (threadIdx.x >> 6);
-    if (n >= nseq) return;
+    __shared__ float sdp[64];
+    __shared__ __attribute__((aligned(16))) float part[WPB][IT * 256];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int64_t n = blockIdx.x;
     float4 q[IT], g[IT];
     load_row<IT>(q, query, D, lane);
     load_row<IT>(g, dout + n * (int64_t)D, D, lane);
     const float sq = sqrtf((float)D);
     const float p = lane < S ? prob[n * S + lane] : 0.f;
-    float mydp = 0.f;
-    for (int s = 0; s < S; ++s) {
-        float4 v[IT];
-        load_row<IT>(v, value + (n * S + s) * (int64_t)D, D, lane);
-        const float dp = dot_rows<IT>(g, v);
-        if (lane == s) mydp = dp;
+    for (int s0 = w; s0 < S; s0 += WPB * PB) {
+        float4 v[PB][IT];
+#pragma unroll
+        for (int b = 0; b < PB; ++b) {
+            const int s = s0 + b * WPB;
+            if (s < S) load_row<IT>(v[b], value + (n * S + s) * (int64_t)D, D, lane);
+        }
+#pragma unroll
+        for (int b = 0; b < PB; ++b) {
+            const int s = s0 + b * WPB;
+            if (s < S) {
+                const float dp = dot_rows<IT>(g, v[b]);
+                if (lane == 0) sdp[s] = dp;
+            }
+        }
     }
+    __syncthreads();
+    const float mydp = lane < S ? sdp[lane] : 0.f;
     const float tot = wave_sum(p * mydp);
     const float dscore = p * (mydp - tot) / sq;
     float4 dq[IT];
 #pragma unroll
     for (int it = 0; it < IT; ++it) dq[it] = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int s = 0; s < S; ++s) {
-        const float ps = __shfl(p, s, 64);
-        const float dsc = __shfl(dscore, s, 64);
-        float4 k[IT], dv[IT], dk[IT];
-        load_row<IT>(k, key + (n * S + s) * (int64_t)D, D, lane);
-        axpy_rows<IT>(dq, dsc, k);
+    for (int s0 = w; s0 < S; s0 += WPB * PB) {
+        float4 k[PB][IT];
 #pragma unroll
-        for (int it = 0; it < IT; ++it) {
-            dv[it] = make_float4(ps * g[it].x, ps * g[it].y, ps * g[it].z, ps * g[it].w);
-            dk[it] = make_float4(dsc * q[it].x, dsc * q[it].y, dsc * q[it].z, dsc * q[it].w);
-            if (tanh_key) {
-                dk[it].x *= 1.f - k[it].x * k[it].x; dk[it].y *= 1.f - k[it].y * k[it].y;
-                dk[it].z *= 1.f - k[it].z * k[it].z; dk[it].w *= 1.f - k[it].w * k[it].w;
-            }
-            if (key_is_value) { dv[it].x += dk[it].x; dv[it].y += dk[it].y; dv[it].z += dk[it].z; dv[it].w += dk[it].w; }
+        for (int b = 0; b < PB; ++b) {
+            const int s = s0 + b * WPB;
+            if (s < S) load_row<IT>(k[b], key + (n * S + s) * (int64_t)D, D, lane);
         }
-        store_row<IT>(dvalue + (n * S + s) * (int64_t)D, dv, D, lane);
-        if (!key_is_value) store_row<IT>(dkeypre + (n * S + s) * (int64_t)D, dk, D, lane);
+#pragma unroll
+        for (int b = 0; b < PB; ++b) {
+            const int s = s0 + b * WPB;
+            if (s >= S) continue;
+            const float ps = __shfl(p, s, 64);
+            const float dsc = __shfl(dscore, s, 64);
+            float4 dv[IT], dk[IT];
+            axpy_rows<IT>(dq, dsc, k[b]);
+#pragma unroll
+            for (int it = 0; it < IT; ++it) {
+                dv[it] = make_float4(ps * g[it].x, ps * g[it].y, ps * g[it].z, ps * g[it].w);
+                dk[it] = make_float4(dsc * q[it].x, dsc * q[it].y, dsc * q[it].z, dsc * q[it].w);
+                if (tanh_key) {
+                    dk[it].x *= 1.f - k[b][it].x * k[b][it].x; dk[it].y *= 1.f - k[b][it].y * k[b][it].y;
+                    dk[it].z *= 1.f - k[b][it].z * k[b][it].z; dk[it].w *= 1.f - k[b][it].w * k[b][it].w;
+                }
+                if (key_is_value) { dv[it].x += dk[it].x; dv[it].y += dk[it].y; dv[it].z += dk[it].z; dv[it].w += dk[it].w; }
+            }
+            store_row<IT>(dvalue + (n * S + s) * (int64_t)D, dv, D, lane);
+            if (!key_is_value) store_row<IT>(dkeypre + (n * S + s) * (int64_t)D, dk, D, lane);
+        }
     }
-    store_row<IT>(dq_part + n * (int64_t)D, dq, D, lane);
+#pragma unroll
+    for (int it = 0; it < IT; ++it) *reinterpret_cast<float4*>(&part[w][(it * 64 + lane) * 4]) = dq[it];
+    __syncthreads();
+    for (int c = threadIdx.x * 4; c < D; c += 1024) {
+        const float4 a0 = *reinterpret_cast<const float4*>(&part[0][c]), a1 = *reinterpret_cast<const float4*>(&part[1][c]);
+        const float4 a2 = *reinterpret_cast<const float4*>(&part[2][c]), a3 = *reinterpret_cast<const float4*>(&part[3][c]);
+        float4 r;
+        r.x = ((a0.x + a1.x) + a2.x) + a3.x; r.y = ((a0.y + a1.y) + a2.y) + a3.y;
+        r.z = ((a0.z + a1.z) + a2.z) + a3.z; r.w = ((a0.w + a1.w) + a2.w) + a3.w;
+        *reinterpret_cast<float4*>(dq_part + n * (int64_t)D + c) = r;
+    }
 }
 
 // ------------------------------------------------------------------ scoring (+ cross entropy)
@@ -285,7 +355,7 @@ int pool_fwd(const float* key, const float* value, const float* table, const int
     if (nseq == 0) return NR_OK;
     if (int rc = check_seq_dims("pooling", S, D)) return rc;
     ProfScope prof(FAM_POOL, s, (double)nseq * (2.0 * S * D * 4 + D * 4));
-    const dim3 grid(cdiv(nseq, WPB));
+    const dim3 grid((unsigned)nseq);
     NR_SEQ_DISPATCH(pool_fwd_kernel, grid, key, value, table, idx, nrows, query, mask, out, prob, nseq, S, D);
     return check_launch("pool_fwd");
 }
@@ -295,7 +365,7 @@ int pool_bwd(const float* key, const float* value, const float* query, const flo
     if (nseq == 0) return NR_OK;
     if (int rc = check_seq_dims("pooling bwd", S, D)) return rc;
     ProfScope prof(FAM_POOL, s, (double)nseq * (4.0 * S * D * 4));
-    const dim3 grid(cdiv(nseq, WPB));
+    const dim3 grid((unsigned)nseq);
     NR_SEQ_DISPATCH(pool_bwd_kernel, grid, key, value, query, prob, dout, dkeypre, dvalue, dq_part, nseq, S, D, tanh_key, key_is_value);
     return check_launch("pool_bwd");
 }

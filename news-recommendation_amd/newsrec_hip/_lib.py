@@ -77,6 +77,8 @@ _SIGS = {
     "nr_tfm_layer_bwd_f32": (c_int, [c_fp, c_fp, c_fp, c_i64, c_i64, c_i64, c_i64, C.POINTER(TfmWeights), c_f, c_u64,
                                      c_u32, C.POINTER(TfmSaved), C.POINTER(TfmGrads), c_fp, c_fp, c_sz, c_fp]),
     "nr_adam_step_f32": (c_int, [c_fp, c_fp, c_fp, c_fp, c_i64, C.c_double, C.c_double, C.c_double, C.c_double, c_i64, c_fp]),
+    "nr_adam_multi_f32": (c_int, [c_int, C.POINTER(c_fp), C.POINTER(c_fp), C.POINTER(c_fp), C.POINTER(c_fp), C.POINTER(c_i64),
+                                  C.c_double, C.c_double, C.c_double, C.c_double, c_i64, c_fp]),
 }
 
 EXPORTS = tuple(_SIGS)

@@ -511,6 +511,18 @@ def adam_step(param, grad, exp_avg, exp_avg_sq, step, lr, beta1=0.9, beta2=0.999
                                  _stream()), "nr_adam_step_f32")
 
 
+def adam_multi(params, grads, exp_avgs, exp_avg_sqs, step, lr, beta1=0.9, beta2=0.999, eps=1e-8):
+    """one launch (per 48 tensors) for every parameter that shares `step`; tensors must be contiguous fp32 on one GPU"""
+    n = len(params)
+    if n == 0:
+        return
+    PT, NT = C.c_void_p * n, C.c_int64 * n
+    tabs = [PT(*[_p(t) for t in ts]) for ts in (params, grads, exp_avgs, exp_avg_sqs)]
+    numel = NT(*[t.numel() for t in params])
+    check(lib().nr_adam_multi_f32(n, tabs[0], tabs[1], tabs[2], tabs[3], numel, lr, beta1, beta2, eps, step, _stream()),
+          "nr_adam_multi_f32")
+
+
 # ----------------------------------------------------------------------------- profiler
 def prof_enable(on=True):
     check(lib().nr_prof_enable(1 if on else 0), "nr_prof_enable")

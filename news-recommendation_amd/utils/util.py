@@ -166,15 +166,21 @@ class HipAdam(torch.optim.Optimizer):
                 loss = closure()
         for group in self.param_groups:
             b1, b2 = group["betas"]
+            by_step = {}                      # tensors that share a step number go into one launch
             for p in group["params"]:
                 if p.grad is None:
                     continue
                 st = self.state[p]
                 if not st:
                     st["step"] = 0
-                    st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
-                    st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                    st["exp_avg"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
+                    st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
                 st["step"] += 1
+                if not p.is_contiguous():     # the kernel walks flat memory; a strided parameter gets the per-tensor path
+                    raise RuntimeError("HipAdam: parameters must be contiguous")
                 g = p.grad if p.grad.is_contiguous() else p.grad.contiguous()
-                ops.adam_step(p, g, st["exp_avg"], st["exp_avg_sq"], int(st["step"]), float(group["lr"]), b1, b2, group["eps"])
+                by_step.setdefault(int(st["step"]), []).append((p, g, st["exp_avg"], st["exp_avg_sq"]))
+            for step, items in by_step.items():
+                ps, gs, ms, vs = zip(*items)
+                ops.adam_multi(ps, gs, ms, vs, step, float(group["lr"]), b1, b2, group["eps"])
         return loss
