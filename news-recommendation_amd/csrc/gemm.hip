@@ -473,7 +473,8 @@ static int launch_tiled(const GemmParams& p, hipStream_t s) {
 }
 
 // dW GEMMs (both operands reduction-major, split-K): the tall 320-row tile when it pads M less than 128-row tiles
-static bool tall_tile(int M) { return cdiv(M, 320) * 320 < cdiv(M, 128) * 128; }
+// (only for long reductions: with few k-tiles per split its 80 MFMAs per wave and k-tile serialise on too few CUs)
+static bool tall_tile(int M, int K) { return K >= 8192 && cdiv(M, 320) * 320 < cdiv(M, 128) * 128; }
 
 size_t gemm_workspace_bytes(int M, int N, int ksplit) {
     return ksplit > 1 ? (size_t)ksplit * M * N * sizeof(float) : 0;
@@ -481,11 +482,11 @@ size_t gemm_workspace_bytes(int M, int N, int ksplit) {
 
 int choose_ksplit(int M, int N, int K) {
     // fill ~2 waves of 256 CUs when the output grid alone cannot (dW GEMMs: tiny MxN, huge K)
-    const int tiles = cdiv(M, tall_tile(M) ? 320 : 128) * cdiv(N, 64);
+    const int tiles = cdiv(M, tall_tile(M, K) ? 320 : 128) * cdiv(N, 64);
     const int kt = cdiv(K, BK);
-    if (tiles >= 256 || kt < 16) return 1;
+    if (tiles >= 256 || kt < 8) return 1;
     int ks = (512 + tiles - 1) / tiles;
-    ks = std::min(ks, kt / 8);
+    ks = std::min(ks, kt / 4);
     return std::max(ks, 1);
 }
 
@@ -524,10 +525,12 @@ int gemm_f32(GemmParams p, bool a_kc, bool b_kc, float* workspace, size_t ws_byt
     // BN=128 only when it wastes no more columns than BN=64
     const bool wide = (cdiv(p.N, 128) * 128 == cdiv(p.N, 64) * 64) && p.N >= 128;
     int rc;
-    if (a_kc && b_kc)        rc = wide ? launch_tiled<true, true, 2, 2>(q, s) : launch_tiled<true, true, 2, 1>(q, s);
-    else if (a_kc && !b_kc)  rc = wide ? launch_tiled<true, false, 2, 2>(q, s) : launch_tiled<true, false, 2, 1>(q, s);
+    // few 128-row tiles (the user tower: 1600 history rows) leave most CUs idle: halve the tile
+    const bool small = (int64_t)cdiv(p.M, 128) * cdiv(p.N, 64) * p.ksplit < 192;
+    if (a_kc && b_kc)        rc = small ? launch_tiled<true, true, 1, 1>(q, s) : wide ? launch_tiled<true, true, 2, 2>(q, s) : launch_tiled<true, true, 2, 1>(q, s);
+    else if (a_kc && !b_kc)  rc = small ? launch_tiled<true, false, 1, 1>(q, s) : wide ? launch_tiled<true, false, 2, 2>(q, s) : launch_tiled<true, false, 2, 1>(q, s);
     else if (!a_kc && !b_kc) {
-        if (!p.conv_on && !wide && (p.epi == EPI_NONE || p.ksplit > 1) && tall_tile(p.M)) rc = launch_tiled<false, false, 5, 1>(q, s);
+        if (!p.conv_on && !wide && (p.epi == EPI_NONE || p.ksplit > 1) && tall_tile(p.M, p.K)) rc = launch_tiled<false, false, 5, 1>(q, s);
         else rc = wide ? launch_tiled<false, false, 2, 2>(q, s) : launch_tiled<false, false, 2, 1>(q, s);
     }
     else { set_error("gemm: layout (A red-major, B k-contig) not built"); return NR_ERR_UNSUPPORTED; }
