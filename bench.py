@@ -78,7 +78,24 @@ def train_flops_per_impression():
     return 3 * ((K + 1 + L) * per_seq(T) + per_seq(L))
 
 
-def cpu_baseline(B, steps=2):
+def pmc_traffic():
+    """HBM bytes per GEMM launch from the committed rocprofv3 PMC passes of this same command
+    (tools/profile.sh -> tools/summarize_profile.py -> profiles/*_counters.json; counters cannot be read
+    from inside the process).  (2*FETCH_SIZE + WRITE_SIZE) KiB, the gfx950 correction of MI355X_MICROARCH.md."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_counters.json")))
+    for f in reversed(files):
+        try:
+            fam = json.load(open(f)).get("gemm_family")
+            if fam and "hbm_bytes_per_launch" in fam:
+                return {"traffic": fam["hbm_bytes_per_launch"], "traffic_unit": "B per launch (PMC)",
+                        "traffic_source": "profiles/" + os.path.basename(f), "mfma_busy_frac_pmc": fam.get("mfma_busy_frac")}
+        except (OSError, ValueError):
+            continue
+    return {"traffic": None}
+
+
+def cpu_baseline(B, steps=16):
     """the oracle's train step (same shapes, same synthetic batch) on this host's cores"""
     from oracle import twotower_oracle as O
     cores = max(1, min(os.cpu_count() or 1, int(os.environ.get("OMP_NUM_THREADS", "0")) or (os.cpu_count() or 1)))
@@ -100,7 +117,7 @@ def cpu_baseline(B, steps=2):
         times.append(time.perf_counter() - t0)
     best = min(times[1:])
     return {"value": round(B / best, 3), "unit": "train impressions/s", "cores": cores, "kind": "port",
-            "sample": f"{steps} timed oracle (torch-fp32 CPU restatement) train steps of B={B} after 1 warm-up, min taken; "
+            "sample": f"{steps} timed oracle (torch-fp32 CPU restatement) train steps of B={B} (~10-15 s of CPU work) after 1 warm-up, min taken; "
                       "eval-mode dropout"}
 
 
@@ -183,7 +200,7 @@ def main():
     gemm_tflops = gm["work_per_step"] / (gm["ms_per_step"] * 1e-3) / 1e12 if gm["ms_per_step"] > 0 else 0.0
     roofline = {"kernel": "gemm_f32_kernel (v_mfma_f32_32x32x2_f32), all GEMM launches of one train step",
                 "bound": "mfma", "achieved": round(gemm_tflops, 2), "peak": PEAK_F32_MATRIX_TFLOPS, "unit": "TFLOP/s",
-                "frac": round(gemm_tflops / PEAK_F32_MATRIX_TFLOPS, 4), "traffic": None,
+                "frac": round(gemm_tflops / PEAK_F32_MATRIX_TFLOPS, 4), **pmc_traffic(),
                 "launches_per_step": gm["launches_per_step"], "avg_launch_ms": round(gm["ms_per_step"] / max(gm["launches_per_step"], 1), 5),
                 "flops_per_step": gm["work_per_step"]}
     hbm = {}

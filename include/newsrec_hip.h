@@ -80,8 +80,11 @@ int nr_conv1d_k3_bwd_f32(const float* dy, const float* x, const float* wpack, in
 
 /* ---- residual + dropout + LayerNorm — TFMSelfOutput / TFMOutput, attention.py:109-113,154-158 ----
  * y = LN(drop(h) + x; eps) * gamma + beta.  s_out (may be NULL, may alias h) receives drop(h)+x,
- * mean/rstd [R] (may be NULL) the row statistics needed by the backward. */
-int nr_add_layernorm_fwd_f32(const float* h, const float* x, const float* gamma, const float* beta, int64_t R, int64_t D, float eps, float p_drop, uint64_t seed, uint32_t site, float* y, float* s_out, float* mean, float* rstd, void* stream);
+ * mean/rstd [R] (may be NULL) the row statistics needed by the backward.
+ * x_period = 0: x is [R,D]; x_period = T > 0: x is [T,D] and row r adds x[r % T] — BERT's position (+ token
+ * type) embeddings added to the gathered word rows before embeddings.LayerNorm (HF BertEmbeddings, reached
+ * from encoder.py:74). */
+int nr_add_layernorm_fwd_f32(const float* h, const float* x, int64_t x_period, const float* gamma, const float* beta, int64_t R, int64_t D, float eps, float p_drop, uint64_t seed, uint32_t site, float* y, float* s_out, float* mean, float* rstd, void* stream);
 /* ds = dLN/ds (also the residual gradient); dh (may be NULL) = dropout-masked ds; dgamma/dbeta [D].
  * ws: nr_layernorm_bwd_ws_bytes(R,D) bytes. */
 size_t nr_layernorm_bwd_ws_bytes(int64_t R, int64_t D);
@@ -89,9 +92,12 @@ int nr_add_layernorm_bwd_f32(const float* dy, const float* s, const float* mean,
 
 /* ---- multi-head self-attention core — TFMSelfAttention, attention.py:87-97 ---------------------
  * qkv [N*S, 3*H*dh] (q | k | v blocks per row), mask [N,S] (1 = real token), ctx [N*S, H*dh].
- * row_max/row_sum [N,H,S] (may be NULL in eval) are the softmax statistics the backward reuses. */
-int nr_mhsa_fwd_f32(const float* qkv, const int64_t* mask, int64_t N, int64_t S, int64_t H, int64_t dh, float p_drop, uint64_t seed, uint32_t site, float* ctx, float* row_max, float* row_sum, void* stream);
-int nr_mhsa_bwd_f32(const float* qkv, const int64_t* mask, const float* ctx, const float* dctx, const float* row_max, const float* row_sum, int64_t N, int64_t S, int64_t H, int64_t dh, float p_drop, uint64_t seed, uint32_t site, float* dqkv, void* stream);
+ * row_max/row_sum [N,H,S] (may be NULL in eval) are the softmax statistics the backward reuses.
+ * mask_mode 0: masked keys get an additive -1e5 in fp32 before the softmax (attention.py:44-49,90);
+ * mask_mode 1: masked keys are excluded and a sequence without any valid key gets zero probabilities — what
+ *   HF BertModel computes under torch SDPA for AllBertNewsEncoder (encoder.py:74; transformers 5.15 / torch 2.10). */
+int nr_mhsa_fwd_f32(const float* qkv, const int64_t* mask, int64_t N, int64_t S, int64_t H, int64_t dh, float p_drop, uint64_t seed, uint32_t site, int mask_mode, float* ctx, float* row_max, float* row_sum, void* stream);
+int nr_mhsa_bwd_f32(const float* qkv, const int64_t* mask, const float* ctx, const float* dctx, const float* row_max, const float* row_sum, int64_t N, int64_t S, int64_t H, int64_t dh, float p_drop, uint64_t seed, uint32_t site, int mask_mode, float* dqkv, void* stream);
 
 /* ---- additive ("query") pooling — scaled_dp_attention, attention.py:6-34 -----------------------
  * out[n,:] = softmax_s(query . key[n,s,:] / sqrt(D) + (1-mask[n,s]) * -1e5) . value[n,s,:]
@@ -151,12 +157,24 @@ typedef struct {
     float *row_sum;   /* [N, H, S]                     */
 } nr_tfm_saved;
 /* y [R,D] = TFMLayer(x [N,S,D], mask [N,S]).  p_drop = 0 -> eval.  Dropout sites: site_base+0
- * (attention probs, attention.py:92), +1 (attention.py:111), +2 (attention.py:156). */
-int nr_tfm_layer_fwd_f32(const float* x, const int64_t* mask, int64_t N, int64_t S, int64_t D, int64_t H, const nr_tfm_weights* w, float p_drop, uint64_t seed, uint32_t site_base, nr_tfm_saved* saved, float* y, void* stream);
+ * (attention probs, attention.py:92), +1 (attention.py:111), +2 (attention.py:156).  mask_mode as in
+ * nr_mhsa_fwd_f32: 0 for the reference's TFMLayer, 1 for the layers of HF BertModel (encoder.py:65,74),
+ * which are this same layer (attention.py copies BERT's structure and parameter names). */
+int nr_tfm_layer_fwd_f32(const float* x, const int64_t* mask, int64_t N, int64_t S, int64_t D, int64_t H, const nr_tfm_weights* w, float p_drop, uint64_t seed, uint32_t site_base, int mask_mode, nr_tfm_saved* saved, float* y, void* stream);
 /* dx [R,D] and all parameter gradients (overwritten, not accumulated).
  * ws: nr_tfm_layer_bwd_ws_bytes(N,S,D) bytes of scratch. */
 size_t nr_tfm_layer_bwd_ws_bytes(int64_t N, int64_t S, int64_t D);
-int nr_tfm_layer_bwd_f32(const float* dy, const float* x, const int64_t* mask, int64_t N, int64_t S, int64_t D, int64_t H, const nr_tfm_weights* w, float p_drop, uint64_t seed, uint32_t site_base, const nr_tfm_saved* saved, nr_tfm_grads* grads, float* dx, void* ws, size_t ws_bytes, void* stream);
+int nr_tfm_layer_bwd_f32(const float* dy, const float* x, const int64_t* mask, int64_t N, int64_t S, int64_t D, int64_t H, const nr_tfm_weights* w, float p_drop, uint64_t seed, uint32_t site_base, int mask_mode, const nr_tfm_saved* saved, nr_tfm_grads* grads, float* dx, void* ws, size_t ws_bytes, void* stream);
+
+/* ---- helpers of the BERT embedding stage (HF BertEmbeddings behind AllBertNewsEncoder, encoder.py:65,74) ----
+ * out[i] = keep(i) ? x[i]/(1-p) : 0 with this library's Philox stream: embeddings.dropout, the one dropout
+ * site that is not followed by a LayerNorm.  The same call on the gradient is its backward. */
+int nr_dropout_f32(const float* x, int64_t n, float p_drop, uint64_t seed, uint32_t site, float* out, void* stream);
+/* out[r,:] = x[r,:] + b[:]  (position rows + token_type row 0) */
+int nr_add_bias_rows_f32(const float* x, const float* b, int64_t R, int64_t D, float* out, void* stream);
+/* out[n] = sum_r x[r,n], deterministic two-stage sum (gradient of a row broadcast: position / token-type rows). */
+size_t nr_colsum_ws_bytes(int64_t R, int64_t N);
+int nr_colsum_f32(const float* x, int64_t R, int64_t N, float* out, void* ws, size_t ws_bytes, void* stream);
 
 /* ---- dense Adam — optim.Adam(lr) in BaseModel.get_optimizer, models/BaseModel.py:45-46 ----------
  * torch defaults (betas 0.9/0.999, eps 1e-8, no weight decay, no amsgrad); step counts from 1.

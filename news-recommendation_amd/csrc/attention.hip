@@ -11,7 +11,6 @@
 
 namespace nr {
 
-constexpr float MASK_FILL = -1e5f;
 
 // cooperative [S, dh] tile copy global(row stride ld) -> LDS rows of DHP+1 floats (zero padded)
 // LDS row stride LDS_LD: DHP+1 (odd: conflict-free when lane i reads row i) or DHP (16-B aligned
@@ -90,16 +89,18 @@ __global__ __launch_bounds__(64) void mhsa_fwd_kernel(const float* __restrict__ 
         for (int j = 0; j < S; ++j) {
             const float acc = dot_bcast<DHP>(q, Ks + j * DHP, 0.f);
             float x = acc / sq;
-            x += mask[(int64_t)n * S + j] ? 0.f : MASK_FILL;
+            x += mask[(int64_t)n * S + j] ? 0.f : dc.mask_fill;
             srow[j] = x;
             m = fmaxf(m, x);
         }
+        if (m == -INFINITY) m = 0.f;             // no valid key (mask_fill = -inf): every exp() below is 0
         float sum = 0.f;
         for (int j = 0; j < S; ++j) {
             const float e = expf(srow[j] - m);
             srow[j] = e;
             sum += e;
         }
+        if (sum == 0.f) sum = 1.f;               // ... and the probabilities are 0, not 0/0
         if (row_max) {
             row_max[((int64_t)n * H + h) * S + i] = m;
             row_sum[((int64_t)n * H + h) * S + i] = sum;
@@ -173,7 +174,7 @@ __global__ __launch_bounds__(64) void mhsa_bwd_kernel(const float* __restrict__ 
                 const float acc = dot_bcast<DHP>(q, Ks + j * DHP, 0.f);
                 const float dpd = dot_bcast<DHP>(go, Vs + j * DHP, 0.f);
                 float x = acc / sq;
-                x += mask[(int64_t)n * S + j] ? 0.f : MASK_FILL;
+                x += mask[(int64_t)n * S + j] ? 0.f : dc.mask_fill;
                 const float p = expf(x - m) / sum;
                 float pd = p;
                 if (dc.p > 0.f) pd *= keep_scale(dc, thr, scale, row_linear, S, j);

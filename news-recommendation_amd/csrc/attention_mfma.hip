@@ -24,7 +24,6 @@
 namespace nr {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
-constexpr float MASK_FILL_M = -1e5f;
 constexpr int HPG = 4;                 // heads per workgroup
 
 __device__ __forceinline__ int krow(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
@@ -199,11 +198,12 @@ __global__ __launch_bounds__(256) void mhsa_fwd_mfma_kernel(const float* __restr
         for (int r = 0; r < 16; ++r) {
             const int j = krow(r, h);
             float x = st[r] / sq;
-            x += (j < S) ? (mask[(int64_t)n * S + j] ? 0.f : MASK_FILL_M) : -INFINITY;
+            x += (j < S) ? (mask[(int64_t)n * S + j] ? 0.f : dc.mask_fill) : -INFINITY;
             st[r] = x;
             m = fmaxf(m, x);
         }
         m = fmaxf(m, __shfl_xor(m, 32, 64));
+        if (m == -INFINITY) m = 0.f;                           // no valid key (mask_fill = -inf): all exp() are 0
         float sum = 0.f;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -212,6 +212,7 @@ __global__ __launch_bounds__(256) void mhsa_fwd_mfma_kernel(const float* __restr
             sum += e;
         }
         sum += __shfl_xor(sum, 32, 64);
+        if (sum == 0.f) sum = 1.f;                             // ... and the probabilities are 0, not 0/0
         const int64_t qrow = ((int64_t)n * H + hd) * S + l31;
         if (row_max && h == 0 && l31 < S) { row_max[qrow] = m; row_sum[qrow] = sum; }
         unsigned bits = 0xFFFFu;
@@ -272,7 +273,7 @@ __global__ __launch_bounds__(256) void mhsa_bwd_mfma_kernel(const float* __restr
             const bool ok = lane < S;
             Ms[lane] = ok ? row_max[qrow0 + lane] : 0.f;
             Ls[lane] = ok ? row_sum[qrow0 + lane] : 1.f;
-            Mk[lane] = ok ? (mask[(int64_t)n * S + lane] ? 0.f : MASK_FILL_M) : -INFINITY;
+            Mk[lane] = ok ? (mask[(int64_t)n * S + lane] ? 0.f : dc.mask_fill) : -INFINITY;
         }
     }
     __syncthreads();

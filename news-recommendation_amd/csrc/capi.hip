@@ -64,6 +64,10 @@ static inline hipStream_t S(void* s) { return reinterpret_cast<hipStream_t>(s); 
 static inline DropoutCfg DC(float p, uint64_t seed, uint32_t site) {
     DropoutCfg d; d.p = p; d.seed = seed; d.site = site; return d;
 }
+// attention: mask_mode 0 = additive -1e5 (reference TFMLayer), 1 = excluded keys + safe softmax (HF BertModel / SDPA)
+static inline DropoutCfg DCA(float p, uint64_t seed, uint32_t site, int mask_mode) {
+    DropoutCfg d = DC(p, seed, site); d.mask_fill = mask_mode ? -INFINITY : -1e5f; return d;
+}
 static inline float* bump(char*& cur, size_t floats) {
     float* p = reinterpret_cast<float*>(cur);
     cur += ((floats * sizeof(float) + 255) / 256) * 256;
@@ -232,11 +236,11 @@ int nr_conv1d_k3_bwd_f32(const float* dy, const float* x, const float* wpack, in
     return conv_unpack_grad(gwf, dw, (int)D, (int)E, s);
 }
 
-int nr_add_layernorm_fwd_f32(const float* h, const float* x, const float* gamma, const float* beta, int64_t R, int64_t D, float eps, float p_drop, uint64_t seed, uint32_t site, float* y, float* s_out, float* mean, float* rstd, void* stream) {
-    NR_CHECK_ARG(R >= 0 && D > 0, "layernorm_fwd: bad sizes");
+int nr_add_layernorm_fwd_f32(const float* h, const float* x, int64_t x_period, const float* gamma, const float* beta, int64_t R, int64_t D, float eps, float p_drop, uint64_t seed, uint32_t site, float* y, float* s_out, float* mean, float* rstd, void* stream) {
+    NR_CHECK_ARG(R >= 0 && D > 0 && x_period >= 0, "layernorm_fwd: bad sizes");
     NR_CHECK_ARG(R == 0 || (h && gamma && beta && y), "layernorm_fwd: null pointer");
     NR_CHECK_ARG(p_drop >= 0.f && p_drop < 1.f, "layernorm_fwd: p_drop %f not in [0,1)", p_drop);
-    return ln_fwd(h, x, gamma, beta, y, s_out, mean, rstd, R, (int)D, eps, DC(p_drop, seed, site), S(stream));
+    return ln_fwd(h, x, gamma, beta, y, s_out, mean, rstd, R, (int)D, eps, DC(p_drop, seed, site), S(stream), x_period);
 }
 
 size_t nr_layernorm_bwd_ws_bytes(int64_t R, int64_t D) {
@@ -262,17 +266,17 @@ int nr_add_layernorm_bwd_f32(const float* dy, const float* s_in, const float* me
     return layernorm_bwd(dy, s_in, mean, rstd, gamma, R, (int)D, DC(p_drop, seed, site), ds, dh, dgamma, dbeta, (char*)ws, S(stream));
 }
 
-int nr_mhsa_fwd_f32(const float* qkv, const int64_t* mask, int64_t N, int64_t Sq, int64_t H, int64_t dh, float p_drop, uint64_t seed, uint32_t site, float* ctx, float* row_max, float* row_sum, void* stream) {
+int nr_mhsa_fwd_f32(const float* qkv, const int64_t* mask, int64_t N, int64_t Sq, int64_t H, int64_t dh, float p_drop, uint64_t seed, uint32_t site, int mask_mode, float* ctx, float* row_max, float* row_sum, void* stream) {
     NR_CHECK_ARG(N >= 0 && Sq > 0 && H > 0 && dh > 0, "mhsa_fwd: bad sizes");
     NR_CHECK_ARG(N == 0 || (qkv && mask && ctx), "mhsa_fwd: null pointer");
     NR_CHECK_ARG((row_max == nullptr) == (row_sum == nullptr), "mhsa_fwd: row_max/row_sum must both be given or both NULL");
-    return mhsa_fwd(qkv, mask, ctx, row_max, row_sum, N, (int)Sq, (int)H, (int)dh, DC(p_drop, seed, site), S(stream));
+    return mhsa_fwd(qkv, mask, ctx, row_max, row_sum, N, (int)Sq, (int)H, (int)dh, DCA(p_drop, seed, site, mask_mode), S(stream));
 }
 
-int nr_mhsa_bwd_f32(const float* qkv, const int64_t* mask, const float* ctx, const float* dctx, const float* row_max, const float* row_sum, int64_t N, int64_t Sq, int64_t H, int64_t dh, float p_drop, uint64_t seed, uint32_t site, float* dqkv, void* stream) {
+int nr_mhsa_bwd_f32(const float* qkv, const int64_t* mask, const float* ctx, const float* dctx, const float* row_max, const float* row_sum, int64_t N, int64_t Sq, int64_t H, int64_t dh, float p_drop, uint64_t seed, uint32_t site, int mask_mode, float* dqkv, void* stream) {
     NR_CHECK_ARG(N >= 0 && Sq > 0 && H > 0 && dh > 0, "mhsa_bwd: bad sizes");
     NR_CHECK_ARG(N == 0 || (qkv && mask && ctx && dctx && row_max && row_sum && dqkv), "mhsa_bwd: null pointer");
-    return mhsa_bwd(qkv, mask, ctx, dctx, row_max, row_sum, dqkv, N, (int)Sq, (int)H, (int)dh, DC(p_drop, seed, site), S(stream));
+    return mhsa_bwd(qkv, mask, ctx, dctx, row_max, row_sum, dqkv, N, (int)Sq, (int)H, (int)dh, DCA(p_drop, seed, site, mask_mode), S(stream));
 }
 
 int nr_query_pool_fwd_f32(const float* key, const float* value, const float* table, const int64_t* idx, int64_t table_rows, const float* query, const int64_t* mask, int64_t nseq, int64_t Sq, int64_t D, float* out, float* prob, void* stream) {
@@ -345,6 +349,25 @@ int nr_adam_step_f32(float* param, const float* grad, float* exp_avg, float* exp
     return adam_f32(param, grad, exp_avg, exp_avg_sq, n, lr, beta1, beta2, eps, step, S(stream));
 }
 
+int nr_dropout_f32(const float* x, int64_t n, float p_drop, uint64_t seed, uint32_t site, float* out, void* stream) {
+    NR_CHECK_ARG(n >= 0 && (n == 0 || (x && out)), "dropout: bad arguments");
+    NR_CHECK_ARG(p_drop > 0.f && p_drop < 1.f, "dropout: p_drop %f not in (0,1)", p_drop);
+    return dropout_f32(x, out, n, DC(p_drop, seed, site), S(stream));
+}
+
+int nr_add_bias_rows_f32(const float* x, const float* b, int64_t R, int64_t D, float* out, void* stream) {
+    NR_CHECK_ARG(R >= 0 && D > 0 && (R == 0 || (x && b && out)), "add_bias_rows: bad arguments");
+    return add_bias_rows_f32(x, b, out, R, (int)D, S(stream));
+}
+
+int nr_colsum_f32(const float* x, int64_t R, int64_t N, float* out, void* ws, size_t ws_bytes, void* stream) {
+    NR_CHECK_ARG(R >= 0 && N > 0 && (R == 0 || x) && out, "colsum: bad arguments");
+    NR_CHECK_ARG(ws && ws_bytes >= nr_colsum_ws_bytes(R, N), "colsum: workspace too small");
+    if (R == 0) return hipMemsetAsync(out, 0, N * sizeof(float), S(stream)) == hipSuccess ? NR_OK : NR_ERR_LAUNCH;
+    return colsum(x, N, R, (int)N, out, (float*)ws, S(stream));
+}
+size_t nr_colsum_ws_bytes(int64_t R, int64_t N) { return pad256((size_t)colsum_chunks(R) * N) + 256; }
+
 int nr_adam_multi_f32(int count, float* const* params, const float* const* grads, float* const* exp_avg, float* const* exp_avg_sq,
                       const int64_t* numel, double lr, double beta1, double beta2, double eps, int64_t step, void* stream) {
     NR_CHECK_ARG(count >= 0 && step >= 1, "adam_multi: bad sizes");
@@ -367,7 +390,7 @@ static int copy_d2d(void* dst, const void* src, size_t bytes, hipStream_t s) {
     return NR_OK;
 }
 
-int nr_tfm_layer_fwd_f32(const float* x, const int64_t* mask, int64_t N, int64_t Sq, int64_t D, int64_t H, const nr_tfm_weights* w, float p_drop, uint64_t seed, uint32_t site_base, nr_tfm_saved* sv, float* y, void* stream) {
+int nr_tfm_layer_fwd_f32(const float* x, const int64_t* mask, int64_t N, int64_t Sq, int64_t D, int64_t H, const nr_tfm_weights* w, float p_drop, uint64_t seed, uint32_t site_base, int mask_mode, nr_tfm_saved* sv, float* y, void* stream) {
     NR_CHECK_ARG(N >= 0 && Sq > 0 && D > 0 && H > 0, "tfm_layer_fwd: bad sizes");
     NR_CHECK_ARG(w && sv && x && mask && y, "tfm_layer_fwd: null pointer");
     NR_CHECK_ARG(D % H == 0, "tfm_layer_fwd: hidden dim %lld not divisible by %lld heads (the reference's dense layers need all_head_size == hidden_dim)", (long long)D, (long long)H);
@@ -394,7 +417,7 @@ int nr_tfm_layer_fwd_f32(const float* x, const int64_t* mask, int64_t N, int64_t
     float* mean2 = sv->stats ? sv->stats + 2 * R : nullptr;
     float* rstd2 = sv->stats ? sv->stats + 3 * R : nullptr;
     if (int rc = linear_fwd(x, D, wqkv, bqkv, R, D, 3 * D, EPI_NONE, sv->qkv, nullptr, s)) return rc;
-    if (int rc = mhsa_fwd(sv->qkv, mask, sv->ctx, sv->row_max, sv->row_sum, N, (int)Sq, (int)H, (int)(D / H), DC(p_drop, seed, site_base), s)) return rc;
+    if (int rc = mhsa_fwd(sv->qkv, mask, sv->ctx, sv->row_max, sv->row_sum, N, (int)Sq, (int)H, (int)(D / H), DCA(p_drop, seed, site_base, mask_mode), s)) return rc;
     if (int rc = linear_fwd(sv->ctx, D, w->wo, w->bo, R, D, D, EPI_NONE, sv->s1, nullptr, s)) return rc;
     if (int rc = ln_fwd(sv->s1, x, w->ln1_g, w->ln1_b, sv->y1, sv->s1, mean1, rstd1, R, (int)D, 1e-12f, DC(p_drop, seed, site_base + 1), s)) return rc;
     if (int rc = linear_fwd(sv->y1, D, w->w1, w->b1, R, D, 4 * D, EPI_GELU, sv->a, sv->z, s)) return rc;
@@ -417,7 +440,7 @@ size_t nr_tfm_layer_bwd_ws_bytes(int64_t N, int64_t Sq, int64_t D) {
     return b + wmax;
 }
 
-int nr_tfm_layer_bwd_f32(const float* dy, const float* x, const int64_t* mask, int64_t N, int64_t Sq, int64_t D, int64_t H, const nr_tfm_weights* w, float p_drop, uint64_t seed, uint32_t site_base, const nr_tfm_saved* sv, nr_tfm_grads* g, float* dx, void* ws, size_t ws_bytes, void* stream) {
+int nr_tfm_layer_bwd_f32(const float* dy, const float* x, const int64_t* mask, int64_t N, int64_t Sq, int64_t D, int64_t H, const nr_tfm_weights* w, float p_drop, uint64_t seed, uint32_t site_base, int mask_mode, const nr_tfm_saved* sv, nr_tfm_grads* g, float* dx, void* ws, size_t ws_bytes, void* stream) {
     NR_CHECK_ARG(N > 0 && Sq > 0 && D > 0 && H > 0 && D % H == 0, "tfm_layer_bwd: bad sizes");
     NR_CHECK_ARG(dy && x && mask && w && sv && g && dx, "tfm_layer_bwd: null pointer");
     NR_CHECK_ARG(sv->qkv && sv->ctx && sv->s1 && sv->y1 && sv->z && sv->a && sv->s2 && sv->stats && sv->row_max && sv->row_sum, "tfm_layer_bwd: missing saved activation");
@@ -460,7 +483,7 @@ int nr_tfm_layer_bwd_f32(const float* dy, const float* x, const int64_t* mask, i
     if (int rc = linear_bwd_input(dh1, D, w->wo, R, D, D, EPI_NONE, nullptr, nullptr, dctx, s)) return rc;
     // attention core
     if (int rc = mhsa_bwd(sv->qkv, mask, sv->ctx, dctx, sv->row_max, sv->row_sum, dqkv, N, (int)Sq, (int)H, (int)(D / H),
-                          DC(p_drop, seed, site_base), s)) return rc;
+                          DCA(p_drop, seed, site_base, mask_mode), s)) return rc;
     // QKV projection: packed dW [3D, D], db [3D]; dx = dqkv Wqkv + ds1 (residual)
     const bool gcontig = contiguous3(g->dwq, g->dwk, g->dwv, DD) && contiguous3(g->dbq, g->dbk, g->dbv, (size_t)D);
     float* dwp = gcontig ? g->dwq : dwqkv;

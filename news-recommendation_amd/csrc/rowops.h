@@ -10,13 +10,17 @@ struct DropoutCfg {
     float p = 0.f;        // drop probability; 0 => identity (eval mode)
     uint64_t seed = 0;    // philox key
     uint32_t site = 0;    // stream id of this dropout site
+    // attention kernels only: additive term of a masked key.  -1e5 = the reference's TFMLayer (attention.py:44-49);
+    // -INFINITY = HF BertModel under torch SDPA (masked keys excluded, a sequence with no valid key gets zero
+    // probabilities = zero context: torch's safe softmax)
+    float mask_fill = -1e5f;
 };
 
 int gather_rows(const float* table, int64_t V, int E, const int64_t* ids, int64_t n, float* out, int* oob_flag, hipStream_t s);
 int scatter_add_rows(const float* grad_rows, const int64_t* ids, int64_t n, int E, int64_t V, int64_t padding_idx,
                      float* grad_table, hipStream_t s);
 int ln_fwd(const float* h, const float* x, const float* gamma, const float* beta, float* y, float* s_out, float* mean,
-           float* rstd, int64_t R, int D, float eps, DropoutCfg dc, hipStream_t s);
+           float* rstd, int64_t R, int D, float eps, DropoutCfg dc, hipStream_t s, int64_t x_period = 0);
 int ln_bwd_blocks(int64_t R);
 int ln_bwd(const float* dy, const float* sin, const float* mean, const float* rstd, const float* gamma, float* ds,
            float* dh, float* dgamma_part, float* dbeta_part, int64_t R, int D, DropoutCfg dc, hipStream_t s);
@@ -27,6 +31,8 @@ int conv_unpack_grad(const float* gwf, float* gw, int D, int E, hipStream_t s);
 int add_f32(const float* a, const float* b, float* o, int64_t n, hipStream_t s);
 int relu_bwd_f32(const float* dy, const float* y, float* o, int64_t n, hipStream_t s);
 int mean_f32(const float* v, int n, float* out, hipStream_t s);
+int dropout_f32(const float* x, float* o, int64_t n, DropoutCfg dc, hipStream_t s);
+int add_bias_rows_f32(const float* x, const float* b, float* o, int64_t R, int D, hipStream_t s);
 int adam_f32(float* p, const float* g, float* m, float* v, int64_t n, double lr, double b1, double b2, double eps, int64_t step,
              hipStream_t s);
 constexpr int ADAM_MAX_TENSORS = 48;   // tensors per launch (the table travels in the kernel arguments)

@@ -104,12 +104,12 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ h
                                                      const float* __restrict__ gamma, const float* __restrict__ beta,
                                                      float* __restrict__ y, float* s_out, float* __restrict__ mean_out,
                                                      float* __restrict__ rstd_out, int64_t R, int D, float eps,
-                                                     DropoutCfg dc) {
+                                                     DropoutCfg dc, int64_t x_period) {
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6);
     if (row >= R) return;
     const float* hr = h + row * D;
-    const float* xr = x ? x + row * D : nullptr;
+    const float* xr = x ? x + (x_period > 0 ? row % x_period : row) * D : nullptr;
     float v[IT][VEC];
     const uint32_t thr = drop_threshold(dc.p);
     const float scale = dc.p > 0.f ? 1.0f / (1.0f - dc.p) : 1.0f;
@@ -183,13 +183,13 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ h
 }
 
 int ln_fwd(const float* h, const float* x, const float* gamma, const float* beta, float* y, float* s_out, float* mean,
-           float* rstd, int64_t R, int D, float eps, DropoutCfg dc, hipStream_t s) {
+           float* rstd, int64_t R, int D, float eps, DropoutCfg dc, hipStream_t s, int64_t x_period) {
     if (R == 0) return NR_OK;
     NR_UNSUPPORTED(D > 64 * 4 * LN_MAXIT, "layernorm: D=%d > %d", D, 64 * 4 * LN_MAXIT);
     ProfScope prof(FAM_LN, s, (double)R * D * 4 * (x ? 4 : 3));
     const int grid = cdiv(R, WAVES_PER_BLOCK);
     const bool vec = (D % 4 == 0) && aligned16(h, x, y, s_out);
-#define NR_LN_FWD(V, I) hipLaunchKernelGGL((ln_fwd_kernel<V, I>), dim3(grid), dim3(256), 0, s, h, x, gamma, beta, y, s_out, mean, rstd, R, D, eps, dc)
+#define NR_LN_FWD(V, I) hipLaunchKernelGGL((ln_fwd_kernel<V, I>), dim3(grid), dim3(256), 0, s, h, x, gamma, beta, y, s_out, mean, rstd, R, D, eps, dc, x_period)
     if (vec) {
         if (D <= 512) NR_LN_FWD(4, 2); else if (D <= 1024) NR_LN_FWD(4, 4); else NR_LN_FWD(4, 8);
     } else {
@@ -457,6 +457,39 @@ int relu_bwd_f32(const float* dy, const float* y, float* o, int64_t n, hipStream
     if (n == 0) return NR_OK;
     hipLaunchKernelGGL(relu_bwd_kernel, dim3((int)std::min<int64_t>(cdiv(n, 256), 8192)), dim3(256), 0, s, dy, y, o, n);
     return check_launch("relu_bwd");
+}
+
+// out[i] = keep(i) ? x[i] / (1-p) : 0   (a dropout site that is not followed by a LayerNorm: BERT's embedding
+// dropout; the same call with the same (seed, site) is its backward)
+__global__ __launch_bounds__(256) void dropout_kernel(const float* __restrict__ x, float* __restrict__ o, int64_t n, DropoutCfg dc) {
+    const uint32_t thr = drop_threshold(dc.p);
+    const float scale = 1.0f / (1.0f - dc.p);
+    const int64_t nq = (n + 3) >> 2;
+    for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < nq; q += (int64_t)gridDim.x * blockDim.x) {
+        const Philox4 rn = philox4x32_10(dc.seed, (uint64_t)q, dc.site);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int64_t i = q * 4 + e;
+            if (i < n) o[i] = philox_pick(rn, e) >= thr ? x[i] * scale : 0.f;
+        }
+    }
+}
+int dropout_f32(const float* x, float* o, int64_t n, DropoutCfg dc, hipStream_t s) {
+    if (n == 0) return NR_OK;
+    ProfScope prof(FAM_MISC, s, (double)n * 8);
+    hipLaunchKernelGGL(dropout_kernel, dim3((int)std::min<int64_t>(cdiv(cdiv(n, 4), 256), 8192)), dim3(256), 0, s, x, o, n, dc);
+    return check_launch("dropout");
+}
+
+// out[r, :] = x[r, :] + b[:]
+__global__ void add_bias_rows_kernel(const float* __restrict__ x, const float* __restrict__ b, float* __restrict__ o, int64_t R, int D) {
+    const int64_t n = R * D;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) o[i] = x[i] + b[i % D];
+}
+int add_bias_rows_f32(const float* x, const float* b, float* o, int64_t R, int D, hipStream_t s) {
+    if (R == 0) return NR_OK;
+    hipLaunchKernelGGL(add_bias_rows_kernel, dim3((int)std::min<int64_t>(cdiv(R * D, 256), 8192)), dim3(256), 0, s, x, b, o, R, D);
+    return check_launch("add_bias_rows");
 }
 
 // mean of a short vector (loss over the batch); one block, fixed order

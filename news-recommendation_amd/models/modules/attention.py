@@ -90,8 +90,11 @@ class TFMLayer(nn.Module):
     C call (QKV GEMM, per-head attention, out-proj, residual+LayerNorm, FFN with erf-GELU,
     residual+LayerNorm) through newsrec_hip.ops.tfm_layer."""
 
-    def __init__(self, hidden_dim, head_num, dropout_p):
+    def __init__(self, hidden_dim, head_num, dropout_p, hf_mask=False):
         super().__init__()
+        # hf_mask: this layer sits inside an HF BertModel (AllBertNewsEncoder): same arithmetic, but masked keys
+        # are excluded the SDPA way instead of getting the reference layer's additive -1e5
+        self.hf_mask = bool(hf_mask)
         if hidden_dim % head_num != 0:
             raise ValueError(f"hidden_dim {hidden_dim} must be divisible by head_num {head_num} "
                              "(the reference's output dense layer requires it too)")
@@ -115,4 +118,4 @@ class TFMLayer(nn.Module):
             attention_mask = torch.ones(hidden_states.shape[:2], dtype=torch.int64, device=hidden_states.device)
         p = self.dropout_p if self.training else 0.0
         seed, site = ops.dropout_stream.next(3) if p > 0 else (0, 0)
-        return ops.tfm_layer(hidden_states, attention_mask, self.head_num, self.kernel_params(), p, seed, site)
+        return ops.tfm_layer(hidden_states, attention_mask, self.head_num, self.kernel_params(), p, seed, site, self.hf_mask)

@@ -110,14 +110,112 @@ class TfmNewsEncoder(BaseNewsEncoder):
         return tok.view(*shape, -1), news.view(*shape[:-1], -1)
 
 
+class _BertEmbeddings(nn.Module):
+    """parameter container with HF BertEmbeddings' names"""
+
+    def __init__(self, cfg):
+        super().__init__()
+        D = cfg["hidden_size"]
+        self.word_embeddings = nn.Embedding(cfg["vocab_size"], D, padding_idx=cfg.get("pad_token_id", 0))
+        self.position_embeddings = nn.Embedding(cfg["max_position_embeddings"], D)
+        self.token_type_embeddings = nn.Embedding(cfg.get("type_vocab_size", 2), D)
+        self.LayerNorm = nn.LayerNorm(D, eps=cfg.get("layer_norm_eps", 1e-12))
+
+
+class _BertEncoder(nn.Module):
+    def __init__(self, cfg):
+        super().__init__()
+        self.layer = nn.ModuleList([TFMLayer(cfg["hidden_size"], cfg["num_attention_heads"], cfg.get("hidden_dropout_prob", 0.1),
+                                             hf_mask=True) for _ in range(cfg["num_hidden_layers"])])
+
+
+class HipBertModel(nn.Module):
+    """HF ``BertModel`` without its pooler (the reference drops it, encoder.py:66), as a parameter container
+    whose state-dict keys equal HF's (embeddings.*, encoder.layer.N.*) and whose arithmetic runs in the HIP
+    kernels: the BERT layer IS the reference's TFMLayer (attention.py copies BERT's structure and names)."""
+
+    def __init__(self, cfg):
+        super().__init__()
+        if cfg.get("hidden_act", "gelu") != "gelu":
+            raise ValueError("HipBertModel: only the exact erf GELU of bert-base is built")
+        if cfg.get("intermediate_size", 4 * cfg["hidden_size"]) != 4 * cfg["hidden_size"]:
+            raise ValueError("HipBertModel: intermediate_size must be 4 x hidden_size (bert-base: 3072 = 4 x 768)")
+        if cfg.get("attention_probs_dropout_prob", 0.1) != cfg.get("hidden_dropout_prob", 0.1):
+            raise ValueError("HipBertModel: the fused layer uses one dropout probability for its three sites")
+        if cfg.get("position_embedding_type", "absolute") != "absolute":
+            raise ValueError("HipBertModel: absolute position embeddings only")
+        self.cfg = dict(cfg)
+        self.embeddings = _BertEmbeddings(cfg)
+        self.encoder = _BertEncoder(cfg)
+        self.dropout_p = float(cfg.get("hidden_dropout_prob", 0.1))
+        std = cfg.get("initializer_range", 0.02)                    # HF _init_weights
+        for m in self.modules():
+            if isinstance(m, nn.Linear):
+                nn.init.normal_(m.weight, std=std)
+                nn.init.zeros_(m.bias)
+            elif isinstance(m, nn.Embedding):
+                nn.init.normal_(m.weight, std=std)
+                if m.padding_idx is not None:
+                    with torch.no_grad():
+                        m.weight[m.padding_idx].zero_()
+
+    @classmethod
+    def from_pretrained(cls, plm_dir):
+        """local directory only (config.json + model.safetensors | pytorch_model.bin); never downloads."""
+        import json
+        with open(os.path.join(plm_dir, "config.json")) as f:
+            cfg = json.load(f)
+        model = cls(cfg)
+        st_path = os.path.join(plm_dir, "model.safetensors")
+        if os.path.exists(st_path):
+            from safetensors.torch import load_file
+            state = load_file(st_path)
+        else:
+            state = torch.load(os.path.join(plm_dir, "pytorch_model.bin"), map_location="cpu", weights_only=True)
+        clean = {}
+        for k, v in state.items():
+            k = k[5:] if k.startswith("bert.") else k
+            if k.startswith("pooler.") or k.endswith("position_ids") or k.startswith("cls."):
+                continue
+            clean[k.replace("LayerNorm.gamma", "LayerNorm.weight").replace("LayerNorm.beta", "LayerNorm.bias")] = v
+        model.load_state_dict(clean, strict=True)
+        return model
+
+    def forward(self, token_id, attn_mask):
+        """ids/mask [M,T] -> last_hidden_state [M,T,D]"""
+        e = self.embeddings
+        p = self.dropout_p if self.training else 0.0
+        seed, site = ops.dropout_stream.next(1) if p > 0 else (0, 0)
+        x = ops.bert_embeddings(e.word_embeddings.weight, e.position_embeddings.weight, e.token_type_embeddings.weight,
+                                e.LayerNorm.weight, e.LayerNorm.bias, token_id, e.LayerNorm.eps, p, seed, site)
+        for layer in self.encoder.layer:
+            x = layer(x, attention_mask=attn_mask)
+        return x
+
+
 class AllBertNewsEncoder(BaseNewsEncoder):
-    """12-layer BERT title encoder ([CLS] vector).  BASELINE config 5 — scheduled after the
-    NRMS path; constructing it raises until its bf16-MFMA kernels land."""
+    """BERT title encoder, news vector = [CLS] state (reference encoder.py:62-77).  ``self.plm`` keeps HF
+    BertModel's parameter names (minus the pooler the reference removes), so reference checkpoints load."""
 
     def __init__(self, manager):
         super().__init__(manager)
-        raise NotImplementedError("AllBertNewsEncoder (-ne bert) is not built yet in the MI355X path; "
-                                  "use -ne cnn or -ne tfm")
+        if getattr(manager, "synthetic_plm", False):
+            self.plm = HipBertModel(dict(
+                vocab_size=manager.vocab_size, hidden_size=manager.plm_dim, num_attention_heads=getattr(manager, "plm_heads", 12),
+                num_hidden_layers=getattr(manager, "plm_layers", 12), intermediate_size=4 * manager.plm_dim,
+                max_position_embeddings=getattr(manager, "plm_max_positions", 512), type_vocab_size=2, layer_norm_eps=1e-12, hidden_dropout_prob=0.1,
+                attention_probs_dropout_prob=0.1))
+        else:
+            if not os.path.isdir(manager.plm_dir):
+                raise FileNotFoundError(f"PLM directory {manager.plm_dir} not found (this build never downloads models)")
+            self.plm = HipBertModel.from_pretrained(manager.plm_dir)
+
+    def forward(self, token_id, attn_mask, token_weight=None):
+        shape = token_id.shape
+        T = shape[-1]
+        tok = self.plm(token_id.reshape(-1, T), attn_mask.reshape(-1, T))
+        news = tok[:, 0].reshape(*shape[:-1], -1)
+        return tok.view(*shape, -1), news
 
 
 class RnnUserEncoder(BaseUserEncoder):

@@ -53,13 +53,13 @@ _SIGS = {
     "nr_conv1d_k3_relu_fwd_f32": (c_int, [c_fp, c_fp, c_fp, c_i64, c_i64, c_i64, c_i64, c_fp, c_fp]),
     "nr_conv1d_k3_bwd_ws_bytes": (c_sz, [c_i64, c_i64, c_i64, c_i64]),
     "nr_conv1d_k3_bwd_f32": (c_int, [c_fp, c_fp, c_fp, c_i64, c_i64, c_i64, c_i64, c_fp, c_fp, c_fp, c_fp, c_sz, c_fp]),
-    "nr_add_layernorm_fwd_f32": (c_int, [c_fp, c_fp, c_fp, c_fp, c_i64, c_i64, c_f, c_f, c_u64, c_u32,
+    "nr_add_layernorm_fwd_f32": (c_int, [c_fp, c_fp, c_i64, c_fp, c_fp, c_i64, c_i64, c_f, c_f, c_u64, c_u32,
                                          c_fp, c_fp, c_fp, c_fp, c_fp]),
     "nr_layernorm_bwd_ws_bytes": (c_sz, [c_i64, c_i64]),
     "nr_add_layernorm_bwd_f32": (c_int, [c_fp, c_fp, c_fp, c_fp, c_fp, c_i64, c_i64, c_f, c_u64, c_u32,
                                          c_fp, c_fp, c_fp, c_fp, c_fp, c_sz, c_fp]),
-    "nr_mhsa_fwd_f32": (c_int, [c_fp, c_fp, c_i64, c_i64, c_i64, c_i64, c_f, c_u64, c_u32, c_fp, c_fp, c_fp, c_fp]),
-    "nr_mhsa_bwd_f32": (c_int, [c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_i64, c_i64, c_i64, c_i64, c_f, c_u64, c_u32,
+    "nr_mhsa_fwd_f32": (c_int, [c_fp, c_fp, c_i64, c_i64, c_i64, c_i64, c_f, c_u64, c_u32, c_int, c_fp, c_fp, c_fp, c_fp]),
+    "nr_mhsa_bwd_f32": (c_int, [c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_i64, c_i64, c_i64, c_i64, c_f, c_u64, c_u32, c_int,
                                 c_fp, c_fp]),
     "nr_query_pool_fwd_f32": (c_int, [c_fp, c_fp, c_fp, c_fp, c_i64, c_fp, c_fp, c_i64, c_i64, c_i64, c_fp, c_fp, c_fp]),
     "nr_query_pool_bwd_ws_bytes": (c_sz, [c_i64, c_i64]),
@@ -71,11 +71,15 @@ _SIGS = {
     "nr_score_ce_bwd_f32": (c_int, [c_fp, c_fp, c_fp, c_fp, c_fp, c_i64, c_i64, c_i64, c_fp, c_fp, c_fp]),
     "nr_score_bwd_f32": (c_int, [c_fp, c_fp, c_fp, c_i64, c_i64, c_i64, c_fp, c_fp, c_fp]),
     "nr_relu_bwd_f32": (c_int, [c_fp, c_fp, c_i64, c_fp, c_fp]),
-    "nr_tfm_layer_fwd_f32": (c_int, [c_fp, c_fp, c_i64, c_i64, c_i64, c_i64, C.POINTER(TfmWeights), c_f, c_u64, c_u32,
+    "nr_tfm_layer_fwd_f32": (c_int, [c_fp, c_fp, c_i64, c_i64, c_i64, c_i64, C.POINTER(TfmWeights), c_f, c_u64, c_u32, c_int,
                                      C.POINTER(TfmSaved), c_fp, c_fp]),
     "nr_tfm_layer_bwd_ws_bytes": (c_sz, [c_i64, c_i64, c_i64]),
     "nr_tfm_layer_bwd_f32": (c_int, [c_fp, c_fp, c_fp, c_i64, c_i64, c_i64, c_i64, C.POINTER(TfmWeights), c_f, c_u64,
-                                     c_u32, C.POINTER(TfmSaved), C.POINTER(TfmGrads), c_fp, c_fp, c_sz, c_fp]),
+                                     c_u32, c_int, C.POINTER(TfmSaved), C.POINTER(TfmGrads), c_fp, c_fp, c_sz, c_fp]),
+    "nr_dropout_f32": (c_int, [c_fp, c_i64, c_f, c_u64, c_u32, c_fp, c_fp]),
+    "nr_add_bias_rows_f32": (c_int, [c_fp, c_fp, c_i64, c_i64, c_fp, c_fp]),
+    "nr_colsum_ws_bytes": (c_sz, [c_i64, c_i64]),
+    "nr_colsum_f32": (c_int, [c_fp, c_i64, c_i64, c_fp, c_fp, c_sz, c_fp]),
     "nr_adam_step_f32": (c_int, [c_fp, c_fp, c_fp, c_fp, c_i64, C.c_double, C.c_double, C.c_double, C.c_double, c_i64, c_fp]),
     "nr_adam_multi_f32": (c_int, [c_int, C.POINTER(c_fp), C.POINTER(c_fp), C.POINTER(c_fp), C.POINTER(c_fp), C.POINTER(c_i64),
                                   C.c_double, C.c_double, C.c_double, C.c_double, c_i64, c_fp]),

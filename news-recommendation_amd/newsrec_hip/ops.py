@@ -220,7 +220,7 @@ def _carve(device, sizes):
 
 class _TFMLayer(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, mask, H, p, seed, site, *params):
+    def forward(ctx, x, mask, H, p, seed, site, mask_mode, *params):
         N, S, D = x.shape
         R = N * S
         train = any(ctx.needs_input_grad)       # False under no_grad / eval-only calls
@@ -231,17 +231,17 @@ class _TFMLayer(torch.autograd.Function):
         W = TfmWeights(*[_p(t) for t in params])
         SV = TfmSaved(_p(wqkv), _p(bqkv), _p(qkv), _p(cx), _p(s1), _p(y1), _p(z) if train else None, _p(a), _p(s2),
                       _p(stats) if train else None, _p(rmax) if train else None, _p(rsum) if train else None)
-        check(lib().nr_tfm_layer_fwd_f32(_p(x), _p(mask), N, S, D, H, C.byref(W), p, seed, site, C.byref(SV), _p(y),
-                                        _stream()), "nr_tfm_layer_fwd_f32")
+        check(lib().nr_tfm_layer_fwd_f32(_p(x), _p(mask), N, S, D, H, C.byref(W), p, seed, site, mask_mode, C.byref(SV),
+                                        _p(y), _stream()), "nr_tfm_layer_fwd_f32")
         if train:
             ctx.save_for_backward(x, mask, buf, *params)
-            ctx.cfg = (N, S, D, H, p, seed, site, sizes)
+            ctx.cfg = (N, S, D, H, p, seed, site, mask_mode, sizes)
         return y
 
     @staticmethod
     def backward(ctx, g):
         x, mask, buf, *params = ctx.saved_tensors
-        N, S, D, H, p, seed, site, sizes = ctx.cfg
+        N, S, D, H, p, seed, site, mask_mode, sizes = ctx.cfg
         g = _f32(g, "grad")
         offs, tot = [], 0
         for s in sizes:
@@ -260,14 +260,16 @@ class _TFMLayer(torch.autograd.Function):
         L = lib()
         nbytes = L.nr_tfm_layer_bwd_ws_bytes(N, S, D)
         ws = _ws(nbytes, g.device)
-        check(L.nr_tfm_layer_bwd_f32(_p(g), _p(x), _p(mask), N, S, D, H, C.byref(W), p, seed, site, C.byref(SV), C.byref(G),
-                                     _p(dx), _p(ws), ws.numel() * 4, _stream()), "nr_tfm_layer_bwd_f32")
-        return (dx, None, None, None, None, None) + tuple(grads[n] for n in _TFM_ORDER)
+        check(L.nr_tfm_layer_bwd_f32(_p(g), _p(x), _p(mask), N, S, D, H, C.byref(W), p, seed, site, mask_mode, C.byref(SV),
+                                     C.byref(G), _p(dx), _p(ws), ws.numel() * 4, _stream()), "nr_tfm_layer_bwd_f32")
+        return (dx, None, None, None, None, None, None) + tuple(grads[n] for n in _TFM_ORDER)
 
 
-def tfm_layer(x, mask, head_num, params, p_drop=0.0, seed=0, site=0):
+def tfm_layer(x, mask, head_num, params, p_drop=0.0, seed=0, site=0, hf_mask=False):
     """TFMLayer.forward (attention.py:173-182).  x [N,S,D] fp32, mask [N,S] int64 (1 = real),
-    params: dict with keys wq,bq,wk,bk,wv,bv,wo,bo,ln1_g,ln1_b,w1,b1,w2,b2,ln2_g,ln2_b."""
+    params: dict with keys wq,bq,wk,bk,wv,bv,wo,bo,ln1_g,ln1_b,w1,b1,w2,b2,ln2_g,ln2_b.
+    hf_mask: key-mask semantics of HF BertModel under SDPA (masked keys excluded; no valid key -> zero
+    context) instead of the reference layer's additive -1e5."""
     x = _f32(x, "hidden_states")
     mask = _i64(mask, "attention_mask")
     if x.dim() != 3 or mask.shape != x.shape[:2]:
@@ -278,7 +280,77 @@ def tfm_layer(x, mask, head_num, params, p_drop=0.0, seed=0, site=0):
         want = {"w1": (4 * D, D), "b1": (4 * D,), "w2": (D, 4 * D)}.get(n, (D, D) if n.startswith("w") else (D,))
         if tuple(t.shape) != want:
             raise NewsrecError(f"tfm_layer: parameter {n} has shape {tuple(t.shape)}, expected {want}")
-    return _TFMLayer.apply(x, mask, int(head_num), float(p_drop), int(seed), int(site), *plist)
+    return _TFMLayer.apply(x, mask, int(head_num), float(p_drop), int(seed), int(site), 1 if hf_mask else 0, *plist)
+
+
+# ----------------------------------------------------------------------------- BERT embedding stage
+def colsum(x2d):
+    """deterministic column sums of a [R,N] matrix -> [N]"""
+    R, N = x2d.shape
+    out = torch.empty(N, dtype=torch.float32, device=x2d.device)
+    L = lib()
+    ws = _ws(L.nr_colsum_ws_bytes(R, N), x2d.device)
+    check(L.nr_colsum_f32(_p(x2d), R, N, _p(out), _p(ws), ws.numel() * 4, _stream()), "nr_colsum_f32")
+    return out
+
+
+class _BertEmbed(torch.autograd.Function):
+    """HF BertEmbeddings: dropout(LayerNorm(word[ids] + position[0..T-1] + token_type[0])) over ids [M,T]."""
+
+    @staticmethod
+    def forward(ctx, word, pos, typ, gamma, beta, ids, eps, p, seed, site):
+        M, T = ids.shape
+        D = word.shape[1]
+        R = M * T
+        L = lib()
+        pt = torch.empty(T, D, dtype=torch.float32, device=word.device)
+        check(L.nr_add_bias_rows_f32(_p(pos), _p(typ), T, D, _p(pt), _stream()), "nr_add_bias_rows_f32")   # pos[:T] + type[0]
+        e = gather_rows(word, ids).view(R, D)
+        y = torch.empty(R, D, dtype=torch.float32, device=word.device)
+        stats = torch.empty(2, R, dtype=torch.float32, device=word.device)
+        check(L.nr_add_layernorm_fwd_f32(_p(e), _p(pt), T, _p(gamma), _p(beta), R, D, eps, 0.0, 0, 0, _p(y), _p(e),
+                                         _p(stats[0]), _p(stats[1]), _stream()), "nr_add_layernorm_fwd_f32")
+        if p > 0:
+            yd = torch.empty_like(y)
+            check(L.nr_dropout_f32(_p(y), y.numel(), p, seed, site, _p(yd), _stream()), "nr_dropout_f32")
+            y = yd
+        ctx.save_for_backward(e, stats, gamma, ids)
+        ctx.cfg = (M, T, D, word.shape[0], pos.shape[0], typ.shape[0], p, seed, site)
+        return y.view(M, T, D)
+
+    @staticmethod
+    def backward(ctx, g):
+        s, stats, gamma, ids = ctx.saved_tensors
+        M, T, D, V, NP, NT, p, seed, site = ctx.cfg
+        R = M * T
+        L = lib()
+        g = _f32(g, "grad").reshape(R, D)
+        if p > 0:
+            gd = torch.empty_like(g)
+            check(L.nr_dropout_f32(_p(g), g.numel(), p, seed, site, _p(gd), _stream()), "nr_dropout_f32")
+            g = gd
+        ds = torch.empty(R, D, dtype=torch.float32, device=g.device)
+        dgamma = torch.empty(D, dtype=torch.float32, device=g.device)
+        dbeta = torch.empty(D, dtype=torch.float32, device=g.device)
+        ws = _ws(L.nr_layernorm_bwd_ws_bytes(R, D), g.device)
+        check(L.nr_add_layernorm_bwd_f32(_p(g), _p(s), _p(stats[0]), _p(stats[1]), _p(gamma), R, D, 0.0, 0, 0, _p(ds), None,
+                                         _p(dgamma), _p(dbeta), _p(ws), ws.numel() * 4, _stream()), "nr_add_layernorm_bwd_f32")
+        dword = torch.zeros(V, D, dtype=torch.float32, device=g.device)
+        check(L.nr_scatter_add_rows_f32(_p(ds), _p(ids), R, D, V, PAD_ID, _p(dword), _stream()), "nr_scatter_add_rows_f32")
+        dpos = torch.zeros(NP, D, dtype=torch.float32, device=g.device)
+        dpos[:T] = colsum(ds.view(M, T * D)).view(T, D)            # every title adds position rows 0..T-1
+        dtyp = torch.zeros(NT, D, dtype=torch.float32, device=g.device)
+        dtyp[0] = colsum(dpos[:T])                                   # ... and token-type row 0 at every token
+        return dword, dpos, dtyp, dgamma, dbeta, None, None, None, None, None
+
+
+def bert_embeddings(word, pos, typ, gamma, beta, ids, eps=LN_EPS, p_drop=0.0, seed=0, site=0):
+    ids = _i64(ids, "token_id")
+    if ids.dim() != 2 or ids.shape[1] > pos.shape[0]:
+        raise NewsrecError(f"bert_embeddings: ids {tuple(ids.shape)} must be [M,T] with T <= {pos.shape[0]} positions")
+    return _BertEmbed.apply(_f32(word, "word_embeddings"), _f32(pos, "position_embeddings"), _f32(typ, "token_type_embeddings"),
+                            _f32(gamma, "embeddings.LayerNorm.weight"), _f32(beta, "embeddings.LayerNorm.bias"), ids,
+                            float(eps), float(p_drop), int(seed), int(site))
 
 
 # ----------------------------------------------------------------------------- projection + query pooling

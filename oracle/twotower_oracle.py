@@ -79,8 +79,12 @@ def _drop(x, keep_mask, p):
     return x * (keep_mask.to(x.dtype) / (1.0 - p))
 
 
-def tfm_layer(P, prefix, x, mask, head_num, drop_masks=None, p=0.1, return_all=False):
+def tfm_layer(P, prefix, x, mask, head_num, drop_masks=None, p=0.1, return_all=False, hf_mask=False):
     """One BERT-style layer.  x [N,S,D], mask [N,S] (0/1 ints).
+    hf_mask=False: the reference's own TFMLayer — masked keys get an additive -1e5 (attention.py:44-49).
+    hf_mask=True: HF BertModel under torch SDPA (bert_news_encoder below) — masked keys are excluded
+    (-inf) and a sequence with NO valid key gets all-zero probabilities (torch's safe softmax), i.e. a zero
+    context vector; checked against transformers 5.15.0 / torch 2.10 in tests/golden/pair_bert_*.npz.
 
     P[prefix + name] uses the reference's keys (attention.self.query.weight …).
     drop_masks: None (eval) or dict with boolean keep-masks 'probs' [N,H,S,S],
@@ -99,10 +103,14 @@ def tfm_layer(P, prefix, x, mask, head_num, drop_masks=None, p=0.1, return_all=F
     q = heads(F.linear(x, g("attention.self.query.weight"), g("attention.self.query.bias")))
     k = heads(F.linear(x, g("attention.self.key.weight"), g("attention.self.key.bias")))
     v = heads(F.linear(x, g("attention.self.value.weight"), g("attention.self.value.bias")))
-    ext = additive_mask(mask)[:, None, None, :]              # attention.py:44-49
     scores = torch.matmul(q, k.transpose(-1, -2))            # attention.py:87
     scores = scores / math.sqrt(dh)                          # attention.py:89
-    probs = torch.softmax(scores + ext, dim=-1)              # attention.py:90
+    if hf_mask:
+        scores = scores.masked_fill(mask[:, None, None, :] == 0, float("-inf"))
+        probs = torch.nan_to_num(torch.softmax(scores, dim=-1), nan=0.0)
+    else:
+        ext = additive_mask(mask)[:, None, None, :]          # attention.py:44-49
+        probs = torch.softmax(scores + ext, dim=-1)          # attention.py:90
     probs_d = _drop(probs, dm.get("probs"), p)               # attention.py:92
     ctx = torch.matmul(probs_d, v).permute(0, 2, 1, 3).contiguous().view(N, S, A)
 
@@ -160,6 +168,35 @@ def tfm_news_encoder(P, token_id, attn_mask, head_num, prefix="newsEncoder.",
     return tok, news
 
 
+def bert_news_encoder(P, token_id, attn_mask, head_num, prefix="newsEncoder.", drop_masks=None):
+    """AllBertNewsEncoder.forward, encoder.py:69-77: HF ``BertModel`` (pooler removed, encoder.py:66) over
+    [M,T] ids with a 2-D attention mask, news vector = last_hidden_state[:,0].
+
+    The arithmetic is third-party (transformers, unpinned by the reference; pinned here to 5.15.0 through
+    tests/golden/pair_bert_*.npz).  Restated from BertModel's published structure:
+      embeddings = LayerNorm(word[ids] + position[0..T-1] + token_type[0]; eps=1e-12), dropout
+      num_hidden_layers x post-LN layer — the same layer as the reference's TFMLayer (attention.py:161-182,
+      which copies BERT's parameter names), except for the key mask (tfm_layer, hf_mask=True).
+    drop_masks: None (eval) or dict: 'emb' [M,T,D] and per layer i 'L{i}' -> tfm_layer's dict."""
+    shp = token_id.shape
+    T = shp[-1]
+    ids = token_id.reshape(-1, T)
+    m = attn_mask.reshape(-1, T)
+    e = prefix + "plm.embeddings."
+    D = P[e + "word_embeddings.weight"].shape[1]
+    x = embedding_lookup(P[e + "word_embeddings.weight"], ids)
+    x = x + P[e + "token_type_embeddings.weight"][0] + P[e + "position_embeddings.weight"][:T]
+    x = F.layer_norm(x, (D,), P[e + "LayerNorm.weight"], P[e + "LayerNorm.bias"], eps=1e-12)
+    dm = drop_masks or {}
+    x = _drop(x, dm.get("emb"), 0.1)
+    i = 0
+    while f"{prefix}plm.encoder.layer.{i}.output.dense.weight" in P:
+        x = tfm_layer(P, f"{prefix}plm.encoder.layer.{i}.", x, m, head_num, dm.get(f"L{i}"), hf_mask=True)
+        i += 1
+    news = x[:, 0].reshape(*shp[:-1], -1)
+    return x.reshape(*shp, -1), news
+
+
 # --------------------------------------------------------------------------
 # user encoders — models/modules/encoder.py:204-327
 # --------------------------------------------------------------------------
@@ -215,6 +252,8 @@ def encode_news(P, kind, token_id, attn_mask, head_num=None, drop_masks=None):
         return cnn_news_encoder(P, token_id, attn_mask)[1]
     if kind == "tfm":
         return tfm_news_encoder(P, token_id, attn_mask, head_num, drop_masks=drop_masks)[1]
+    if kind == "bert":
+        return bert_news_encoder(P, token_id, attn_mask, head_num, drop_masks=drop_masks)[1]
     raise ValueError(kind)
 
 

@@ -10,7 +10,7 @@ GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 def load_golden(tag):
     z = np.load(os.path.join(GOLDEN, tag + ".npz"), allow_pickle=False)
     blob = {k: z[k] for k in z.files}
-    meta = dict(zip("V E D H T L K B Nn".split(), [int(v) for v in blob["meta"]])) if "meta" in blob and len(blob["meta"]) == 9 else {}
+    meta = dict(zip("V E D H T L K B Nn NL".split(), [int(v) for v in blob["meta"]])) if "meta" in blob and len(blob["meta"]) in (9, 10) else {}
     if "w_seed" in blob:
         from golden.seeded import seeded_state
         names = [str(n) for n in blob["w_names"]]

@@ -164,7 +164,7 @@ def test_add_layernorm(ops, R, D, p):
     y = torch.empty(R, D, device="cuda"); s = torch.empty(R, D, device="cuda")
     mean = torch.empty(R, device="cuda"); rstd = torch.empty(R, device="cuda")
     st = torch.cuda.current_stream().cuda_stream
-    ops.check(L.nr_add_layernorm_fwd_f32(hg.data_ptr(), xg.data_ptr(), gam.data_ptr(), bet.data_ptr(), R, D,
+    ops.check(L.nr_add_layernorm_fwd_f32(hg.data_ptr(), xg.data_ptr(), 0, gam.data_ptr(), bet.data_ptr(), R, D,
                                          1e-12, p, seed, site, y.data_ptr(), s.data_ptr(), mean.data_ptr(), rstd.data_ptr(), st))
     assert relerr(y, y_ref) < FP32_TOL
     assert relerr(s, s_ref) < FP32_TOL
@@ -212,7 +212,7 @@ def test_mhsa(ops, N, S, H, dh, p):
     qg, mg = qkv.cuda(), mask.cuda()
     ctx = torch.empty(N * S, A, device="cuda")
     rmax = torch.empty(N, H, S, device="cuda"); rsum = torch.empty(N, H, S, device="cuda")
-    ops.check(L.nr_mhsa_fwd_f32(qg.data_ptr(), mg.data_ptr(), N, S, H, dh, p, seed, site, ctx.data_ptr(), rmax.data_ptr(),
+    ops.check(L.nr_mhsa_fwd_f32(qg.data_ptr(), mg.data_ptr(), N, S, H, dh, p, seed, site, 0, ctx.data_ptr(), rmax.data_ptr(),
                                 rsum.data_ptr(), st))
     # rows of partially masked / unmasked sequences: fp32 bar.  Fully masked rows with DIFFERENT tokens
     # (sequence 0) are ill-conditioned by construction (score - 1e5 quantised to 2^-7): looser bound.
@@ -224,7 +224,7 @@ def test_mhsa(ops, N, S, H, dh, p):
     dq = torch.empty(N * S, 3 * A, device="cuda")
     dcg = dctx.cuda()
     ops.check(L.nr_mhsa_bwd_f32(qg.data_ptr(), mg.data_ptr(), ctx.data_ptr(), dcg.data_ptr(), rmax.data_ptr(), rsum.data_ptr(),
-                                N, S, H, dh, p, seed, site, dq.data_ptr(), st))
+                                N, S, H, dh, p, seed, site, 0, dq.data_ptr(), st))
     if N > 2:
         assert relerr(dq[2 * S:], qr.grad[2 * S:]) < 2e-5
 
@@ -242,7 +242,7 @@ def test_mhsa_masked_quantisation_exact(ops):
     L = ops.lib()
     ctx = torch.empty(N * S, dh, device="cuda")
     qg, mg = qkv.cuda(), mask.cuda()
-    ops.check(L.nr_mhsa_fwd_f32(qg.data_ptr(), mg.data_ptr(), N, S, H, dh, 0.0, 0, 0, ctx.data_ptr(), None, None,
+    ops.check(L.nr_mhsa_fwd_f32(qg.data_ptr(), mg.data_ptr(), N, S, H, dh, 0.0, 0, 0, 0, ctx.data_ptr(), None, None,
                                 torch.cuda.current_stream().cuda_stream))
     assert relerr(ctx, ref) < 1e-6
 

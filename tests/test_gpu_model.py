@@ -21,7 +21,9 @@ def build_model(meta, ne, ue):
     from models.modules import encoder as E
     mgr = make_manager(plm_dim=meta["E"], hidden_dim=meta["D"], head_num=meta["H"], his_size=meta["L"],
                        sequence_length=meta["T"], negative_num=meta["K"], vocab_size=meta["V"])
-    news = {"cnn": E.CnnNewsEncoder, "tfm": E.TfmNewsEncoder}[ne](mgr)
+    if ne == "bert":
+        mgr.plm_heads, mgr.plm_layers, mgr.plm_max_positions = meta["H"], meta["NL"], 64
+    news = {"cnn": E.CnnNewsEncoder, "tfm": E.TfmNewsEncoder, "bert": E.AllBertNewsEncoder}[ne](mgr)
     user = {"rnn": E.RnnUserEncoder, "sum": E.SumUserEncoder, "avg": E.AvgUserEncoder, "attn": E.AttnUserEncoder,
             "tfm": E.TfmUserEncoder}[ue](mgr)
     return TwoTowerModel(mgr, news, user), mgr
@@ -36,7 +38,7 @@ def check_against_golden(tag, ne, ue):
     for m in model.modules():
         if hasattr(m, "dropout_p"):
             m.dropout_p = 0.0
-    assert model.name == "TwoTower-{}-{}".format(ne.capitalize(), ue.capitalize())
+    assert model.name == "TwoTower-{}-{}".format({"bert": "AllBert"}.get(ne, ne.capitalize()), ue.capitalize())
     tok, cdd = model._encode_news(X)
     _, his = model._encode_news(X, cdd=False)
     user = model._encode_user(X)
@@ -77,6 +79,13 @@ def check_against_golden(tag, ne, ue):
 @pytest.mark.parametrize("ne,ue", PAIRS)
 def test_pair_matches_reference_golden(ne, ue):
     check_against_golden(f"pair_{ne}_{ue}", ne, ue)
+
+
+@pytest.mark.parametrize("ue", ["attn", "tfm"])
+def test_bert_pair_matches_reference_golden(ue):
+    """AllBertNewsEncoder (2-layer random BERT) + user encoder against the reference's HF BertModel outputs,
+    incl. the all-PAD news (no valid key: SDPA's zero context) and every gradient."""
+    check_against_golden(f"pair_bert_{ue}", "bert", ue)
 
 
 def test_nrms_shape_matches_reference_golden():

@@ -89,3 +89,10 @@ def test_metrics_match_reference():
     assert [res["auc"], res["mean_mrr"], res["ndcg@5"], res["ndcg@10"]] == z["result"].tolist()
     for ws, r, s, e, n in z["shards"]:
         assert O.sequential_shard(int(n), int(ws), int(r)) == (int(s), int(e))
+
+
+@pytest.mark.parametrize("ue", ["attn", "tfm"])
+def test_bert_pair_matches_reference(ue):
+    """AllBertNewsEncoder (HF BertModel, transformers 5.15.0 in the build container): third-party arithmetic,
+    pinned only through these vectors (tests/golden/make_golden_bert.py)."""
+    _run(f"pair_bert_{ue}", "bert", ue)
