@@ -95,6 +95,66 @@ def pmc_traffic():
     return {"traffic": None}
 
 
+def hbm_kernel_leg(model, B):
+    """each HBM-bound kernel of the path alone, at the shape it has in the headline workload (train step at
+    per-GPU batch B) or in cached evaluation, timed with events on the launch stream; GB/s = algorithmic bytes
+     / time.  Tables larger than the 256 MB Infinity Cache are used where the real one is (the
+    news-vector cache is 86 MB at 300-d: cache-resident in production too)."""
+    from newsrec_hip import ops
+    dev = "cuda"
+    g = torch.Generator().manual_seed(3)
+    M, R = B * (K + 1 + L), B * (K + 1 + L) * T
+
+    def timed(fn, reps=20):
+        for _ in range(3):
+            fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / reps * 1e-3
+
+    out = {}
+
+    def add(name, nbytes, fn, note):
+        t = timed(fn)
+        out[name] = {"GB/s": round(nbytes / t / 1e9, 1), "frac_of_8TBs": round(nbytes / t / 1e9 / PEAK_HBM_GBS, 4),
+                     "us": round(t * 1e6, 1), "MB": round(nbytes / 1e6, 1), "shape": note}
+
+    table = model.newsEncoder.embedding.weight.detach()
+    ids = torch.randint(1, V, (M, T), generator=g).to(dev)
+    add("token_gather", 2.0 * R * E * 4 + 8.0 * R, lambda: ops.gather_rows(table, ids), f"{R} token rows x {E} f32 from the {V}x{E} table")
+    x = torch.randn(M, T, D, generator=g).to(dev)
+    key = torch.tanh(torch.randn(M, T, D, generator=g)).to(dev)
+    q = torch.randn(1, D, generator=g).to(dev)
+    msk = torch.ones(M, T, dtype=torch.int64, device=dev)
+    add("news_pooling_fwd", M * (2.0 * T * D * 4 + D * 4), lambda: ops.query_pool(key, x, q, msk), f"{M} titles x {T} tokens x {D}")
+    h, xx = torch.randn(R, D, generator=g).to(dev), torch.randn(R, D, generator=g).to(dev)
+    gam, bet = torch.ones(D, device=dev), torch.zeros(D, device=dev)
+    y = torch.empty(R, D, device=dev)
+    L_ = ops.lib()
+    st = torch.cuda.current_stream().cuda_stream
+    add("add_layernorm_fwd", 3.0 * R * D * 4, lambda: ops.check(L_.nr_add_layernorm_fwd_f32(
+        h.data_ptr(), xx.data_ptr(), 0, gam.data_ptr(), bet.data_ptr(), R, D, 1e-12, 0.0, 0, 0, y.data_ptr(), None, None, None, st), "ln"),
+        f"{R} rows x {D} (read h, x; write y)")
+    # cached evaluation kernels: Re rows of (Ce candidates, L history ids) against the [Nn, D] cache
+    Re, Ce = 32768, 20
+    cache = torch.randn(NEWS_DEV, D, generator=g).to(dev)
+    cdd_idx = torch.randint(0, NEWS_DEV, (Re, Ce), generator=g).to(dev)
+    his_idx = torch.randint(0, NEWS_DEV, (Re, L), generator=g).to(dev)
+    user = torch.randn(Re, D, generator=g).to(dev)
+    add("eval_gather_dot_scoring", Re * ((Ce + 1.0) * D * 4 + Ce * 8 + Ce * 4), lambda: ops.score_from_table(cache, cdd_idx, user),
+        f"{Re} rows x {Ce} candidates gathered from the {NEWS_DEV}x{D} cache")
+    add("eval_history_attn_pool", Re * (2.0 * L * D * 4 + L * 8 + D * 4), lambda: ops.pool_from_table(cache, his_idx, q),
+        f"{Re} rows x {L} history vectors gathered (key and value passes)")
+    add("eval_history_sum", Re * (1.0 * L * D * 4 + L * 8 + D * 4), lambda: ops.seq_reduce_from_table(cache, his_idx),
+        f"{Re} rows x {L} history vectors gathered")
+    return out
+
+
 def cpu_baseline(B, steps=16):
     """the oracle's train step (same shapes, same synthetic batch) on this host's cores"""
     from oracle import twotower_oracle as O
@@ -203,12 +263,14 @@ def main():
                 "frac": round(gemm_tflops / PEAK_F32_MATRIX_TFLOPS, 4), **pmc_traffic(),
                 "launches_per_step": gm["launches_per_step"], "avg_launch_ms": round(gm["ms_per_step"] / max(gm["launches_per_step"], 1), 5),
                 "flops_per_step": gm["work_per_step"]}
-    hbm = {}
+    hbm_step = {}
     for name in ("gather", "layernorm", "pool", "score", "scatter_add"):
         f = fam[name]
         if f["ms_per_step"] > 0:
             gbs = f["work_per_step"] / (f["ms_per_step"] * 1e-3) / 1e9
-            hbm[name] = {"GB/s": round(gbs, 1), "frac_of_8TBs": round(gbs / PEAK_HBM_GBS, 4), "ms_per_step": f["ms_per_step"]}
+            hbm_step[name] = {"GB/s": round(gbs, 1), "frac_of_8TBs": round(gbs / PEAK_HBM_GBS, 4), "ms_per_step": f["ms_per_step"]}
+    with torch.no_grad():
+        hbm = hbm_kernel_leg(model, B)
 
     out = {
         "metric": "train impressions/sec (node), NRMS-shape MIND-large; eval impressions/sec",
@@ -220,7 +282,7 @@ def main():
                    "per_gpu_batch": B, "global_batch": B * world, "vocab": V, "parallelism": f"dp{world}"},
         "loss": round(final_loss, 5),
         "model_tflops": round(value * train_flops_per_impression() / 1e12, 2),
-        "roofline": roofline, "hbm_kernels": hbm, "kernel_ms_per_step": {k: v["ms_per_step"] for k, v in fam.items()},
+        "roofline": roofline, "hbm_kernels": hbm, "hbm_families_in_step": hbm_step, "kernel_ms_per_step": {k: v["ms_per_step"] for k, v in fam.items()},
     }
 
     # ---- cached evaluation leg (BASELINE config 4 shape, per GPU): cache build + impression scoring
