@@ -166,6 +166,18 @@ int nr_tfm_layer_fwd_f32(const float* x, const int64_t* mask, int64_t N, int64_t
 size_t nr_tfm_layer_bwd_ws_bytes(int64_t N, int64_t S, int64_t D);
 int nr_tfm_layer_bwd_f32(const float* dy, const float* x, const int64_t* mask, int64_t N, int64_t S, int64_t D, int64_t H, const nr_tfm_weights* w, float p_drop, uint64_t seed, uint32_t site_base, int mask_mode, const nr_tfm_saved* saved, nr_tfm_grads* grads, float* dx, void* ws, size_t ws_bytes, void* stream);
 
+/* ---- GRU user encoder — RnnUserEncoder, models/modules/encoder.py:204-233 -----------------------------
+ * One-layer nn.GRU(Din, H, batch_first) over x [B,L,Din], packed by len_b = sum_l mask[b,l] (>= 1: the
+ * reference sets his_mask[b,0] = 1 for an empty history, dataset.py:140-141); the user vector is the state
+ * after len_b steps = hall[L] (states freeze when a sequence ends).  torch layouts: w_ih [3H,Din], w_hh [3H,H],
+ * gate order r|z|n.  Caller-allocated: gi [B*L,3H], gh [B,3H] scratch, hall [(L+1),B,H] (hall[0] is zeroed
+ * here), gates [L,B,4H] (r,z,n,gh_n; NULL = eval, nothing saved), lens [B] int32.  No host sync
+ * (the reference's lens.cpu() at encoder.py:227 is gone). */
+int nr_gru_fwd_f32(const float* x, const int64_t* mask, const float* w_ih, const float* w_hh, const float* b_ih, const float* b_hh, int64_t B, int64_t L, int64_t Din, int64_t H, float* gi, float* gh, float* hall, float* gates, int32_t* lens, void* stream);
+/* dh_out [B,H] = gradient of hall[L]; dx [B*L,Din] may be NULL; dw_ih, dw_hh, db_ih, db_hh are overwritten. */
+size_t nr_gru_bwd_ws_bytes(int64_t B, int64_t L, int64_t Din, int64_t H);
+int nr_gru_bwd_f32(const float* dh_out, const float* x, const float* w_ih, const float* w_hh, int64_t B, int64_t L, int64_t Din, int64_t H, const float* hall, const float* gates, const int32_t* lens, float* dx, float* dw_ih, float* dw_hh, float* db_ih, float* db_hh, void* ws, size_t ws_bytes, void* stream);
+
 /* ---- helpers of the BERT embedding stage (HF BertEmbeddings behind AllBertNewsEncoder, encoder.py:65,74) ----
  * out[i] = keep(i) ? x[i]/(1-p) : 0 with this library's Philox stream: embeddings.dropout, the one dropout
  * site that is not followed by a LayerNorm.  The same call on the gradient is its backward. */

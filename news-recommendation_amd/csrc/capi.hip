@@ -500,4 +500,60 @@ int nr_tfm_layer_bwd_f32(const float* dy, const float* x, const int64_t* mask, i
     return linear_bwd_input(dqkv, 3 * D, wqkv, R, 3 * D, D, EPI_ADD_AUX, ds1, nullptr, dx, s);
 }
 
+// ------------------------------------------------------------------------------------ GRU user encoder
+int nr_gru_fwd_f32(const float* x, const int64_t* mask, const float* w_ih, const float* w_hh, const float* b_ih, const float* b_hh,
+                   int64_t B, int64_t L, int64_t Din, int64_t H, float* gi, float* gh, float* hall, float* gates, int32_t* lens,
+                   void* stream) {
+    NR_CHECK_ARG(B >= 0 && L > 0 && Din > 0 && H > 0, "gru_fwd: bad sizes");
+    if (B == 0) return NR_OK;
+    NR_CHECK_ARG(x && mask && w_ih && w_hh && b_ih && b_hh && gi && gh && hall && lens, "gru_fwd: null pointer");
+    hipStream_t s = S(stream);
+    if (int rc = gru_lens(mask, lens, (int)B, (int)L, s)) return rc;
+    if (hipMemsetAsync(hall, 0, (size_t)B * H * sizeof(float), s) != hipSuccess) { set_error("gru_fwd: memset failed"); return NR_ERR_LAUNCH; }
+    // input half of every step in one GEMM: GI[b*L+t, :] = x[b,t,:] W_ih^T + b_ih
+    if (int rc = linear_fwd(x, Din, w_ih, b_ih, B * L, Din, 3 * H, EPI_NONE, gi, nullptr, s)) return rc;
+    for (int t = 0; t < (int)L; ++t) {
+        const float* hp = hall + (size_t)t * B * H;
+        if (int rc = linear_fwd(hp, H, w_hh, b_hh, B, H, 3 * H, EPI_NONE, gh, nullptr, s)) return rc;
+        if (int rc = gru_gate_fwd(gi, gh, hp, lens, hall + (size_t)(t + 1) * B * H, gates ? gates + (size_t)t * B * 4 * H : nullptr,
+                                  (int)B, (int)L, (int)H, t, s)) return rc;
+    }
+    return NR_OK;
+}
+
+size_t nr_gru_bwd_ws_bytes(int64_t B, int64_t L, int64_t Din, int64_t H) {
+    return 2 * pad256((size_t)B * L * 3 * H) + 3 * pad256((size_t)B * H) +
+           std::max(bwd_weight_ws(B * L, 3 * H, H, true), bwd_weight_ws(B * L, 3 * H, Din, true)) + 1024;
+}
+
+int nr_gru_bwd_f32(const float* dh_out, const float* x, const float* w_ih, const float* w_hh, int64_t B, int64_t L, int64_t Din,
+                   int64_t H, const float* hall, const float* gates, const int32_t* lens, float* dx, float* dw_ih, float* dw_hh,
+                   float* db_ih, float* db_hh, void* ws, size_t ws_bytes, void* stream) {
+    NR_CHECK_ARG(B > 0 && L > 0 && Din > 0 && H > 0, "gru_bwd: bad sizes");
+    NR_CHECK_ARG(dh_out && x && w_ih && w_hh && hall && gates && lens && dw_ih && dw_hh && db_ih && db_hh, "gru_bwd: null pointer");
+    NR_CHECK_ARG(ws && ws_bytes >= nr_gru_bwd_ws_bytes(B, L, Din, H), "gru_bwd: workspace too small");
+    hipStream_t s = S(stream);
+    char* cur = (char*)ws;
+    float* dgi = bump(cur, (size_t)B * L * 3 * H);           // rows b*L + t  (the order of x)
+    float* dgh = bump(cur, (size_t)B * L * 3 * H);           // rows t*B + b  (the order of hall)
+    float* direct = bump(cur, (size_t)B * H);                 // dh_t * z
+    float* pp[2] = {bump(cur, (size_t)B * H), bump(cur, (size_t)B * H)};
+    const size_t rest = ws_bytes - (size_t)(cur - (char*)ws);
+    const float* dh = dh_out;
+    int k = 0;
+    for (int t = (int)L - 1; t >= 0; --t) {
+        float* dgh_t = dgh + (size_t)t * B * 3 * H;
+        if (int rc = gru_gate_bwd(dh, gates + (size_t)t * B * 4 * H, hall + (size_t)t * B * H, lens, dgi, dgh_t, direct, (int)B,
+                                  (int)L, (int)H, t, s)) return rc;
+        // dh_{t-1} = dh_t * z  +  dGH_t W_hh
+        if (int rc = linear_bwd_input(dgh_t, 3 * H, w_hh, B, 3 * H, H, EPI_ADD_AUX, direct, nullptr, pp[k], s)) return rc;
+        dh = pp[k];
+        k ^= 1;
+    }
+    if (int rc = linear_bwd_weight(dgh, 3 * H, hall, H, B * L, 3 * H, H, dw_hh, db_hh, cur, rest, 0, 0, s)) return rc;
+    if (int rc = linear_bwd_weight(dgi, 3 * H, x, Din, B * L, 3 * H, Din, dw_ih, db_ih, cur, rest, 0, 0, s)) return rc;
+    if (dx) return linear_bwd_input(dgi, 3 * H, w_ih, B * L, 3 * H, Din, EPI_NONE, nullptr, nullptr, dx, s);
+    return NR_OK;
+}
+
 }  // extern "C"

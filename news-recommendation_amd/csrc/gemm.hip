@@ -387,7 +387,7 @@ __global__ __launch_bounds__(256, (WM * NJ <= 2) ? 4 : (WM * NJ <= 4 ? 3 : 2)) v
         if (more) lstore();
         __syncthreads();
     }
-    if (kt_full < kt_end) {                  // ragged last tile: only the quads that hold k < K (the loader zero-fills)
+    if (kt_begin < kt_end && kt_full < kt_end) {   // ragged last tile (an empty split-K slice owns none): only the quads that hold k < K (the loader zero-fills)
         const int nkq = (p.K - kt_full * BK + 7) >> 3;
         for (int kq = 0; kq < nkq; ++kq) {
             Frags f;

@@ -1,6 +1,7 @@
 // internal interface of the per-sequence kernels (attention.hip, seqops.hip)
 #pragma once
 #include "common.h"
+#include <algorithm>
 #include "rowops.h"
 
 namespace nr {
@@ -28,5 +29,13 @@ int score_bwd(const float* cdd, const float* user, const int64_t* label, const f
 int seq_reduce(const float* x, const float* table, const int64_t* idx, int64_t nrows, float* out, int64_t nseq, int S, int D,
                int mean, hipStream_t s);
 int seq_broadcast(const float* dout, float* dx, int64_t nseq, int S, int D, float scale, hipStream_t s);
+
+
+// GRU recurrence halves (gru.hip)
+int gru_lens(const int64_t* mask, int* lens, int B, int L, hipStream_t s);
+int gru_gate_fwd(const float* gi, const float* gh, const float* hprev, const int* lens, float* hnext, float* saved, int B, int L,
+                 int H, int t, hipStream_t s);
+int gru_gate_bwd(const float* dh, const float* saved, const float* hprev, const int* lens, float* dgi, float* dgh, float* dh_direct,
+                 int B, int L, int H, int t, hipStream_t s);
 
 }  // namespace nr

@@ -4,14 +4,12 @@ Same class names, constructor argument (``manager``), forward signatures and
 parameter names as the reference's models/modules/encoder.py, so its
 checkpoints load and ``main.twotower`` picks them by the same flags.  torch
 modules are parameter containers; all arithmetic goes through newsrec_hip.ops
-(the one exception, by SURVEY §8-a5, is the GRU cell of ``RnnUserEncoder``,
-which stays on torch.nn.GRU / MIOpen this round).
+(including the GRU of ``RnnUserEncoder``).
 """
 import os
 
 import torch
 import torch.nn as nn
-from torch.nn.utils.rnn import pack_padded_sequence
 
 from newsrec_hip import ops
 from .attention import TFMLayer
@@ -219,8 +217,9 @@ class AllBertNewsEncoder(BaseNewsEncoder):
 
 
 class RnnUserEncoder(BaseUserEncoder):
-    """final GRU state over the clicked-news vectors (default -ue).  Delegated to torch.nn.GRU
-    (MIOpen) this round — SURVEY §8 a5 / f3 list the persistent HIP GRU as a later row."""
+    """final GRU state over the clicked-news vectors (the default -ue of main.twotower).  ``self.rnn`` is an
+    nn.GRU used as a parameter container only (reference key names rnn.weight_ih_l0 …); the recurrence runs
+    in the HIP library (input half as one MFMA GEMM, 2 small launches per step, no lens.cpu() sync)."""
 
     def __init__(self, manager):
         super().__init__()
@@ -230,10 +229,9 @@ class RnnUserEncoder(BaseUserEncoder):
                 nn.init.orthogonal_(param)
 
     def forward(self, news_embedding, his_mask):
-        lens = his_mask.sum(dim=-1).cpu()
-        packed = pack_padded_sequence(news_embedding, lens, batch_first=True, enforce_sorted=False)
-        _, h = self.rnn(packed)
-        return h.transpose(0, 1)
+        r = self.rnn
+        h = ops.gru_final_state(news_embedding, his_mask, r.weight_ih_l0, r.weight_hh_l0, r.bias_ih_l0, r.bias_hh_l0)
+        return h.unsqueeze(1)
 
 
 class SumUserEncoder(BaseUserEncoder):

@@ -283,6 +283,54 @@ def tfm_layer(x, mask, head_num, params, p_drop=0.0, seed=0, site=0, hf_mask=Fal
     return _TFMLayer.apply(x, mask, int(head_num), float(p_drop), int(seed), int(site), 1 if hf_mask else 0, *plist)
 
 
+# ----------------------------------------------------------------------------- GRU user encoder
+class _GRUFinal(torch.autograd.Function):
+    """final state of nn.GRU over a packed batch (RnnUserEncoder.forward, encoder.py:216-233)."""
+
+    @staticmethod
+    def forward(ctx, x, mask, w_ih, w_hh, b_ih, b_hh):
+        B, L, Din = x.shape
+        H = w_hh.shape[1]
+        train = any(ctx.needs_input_grad)
+        dev = x.device
+        gi = torch.empty(B * L, 3 * H, dtype=torch.float32, device=dev)
+        gh = torch.empty(B, 3 * H, dtype=torch.float32, device=dev)
+        hall = torch.empty(L + 1, B, H, dtype=torch.float32, device=dev)
+        gates = torch.empty(L, B, 4 * H, dtype=torch.float32, device=dev) if train else None
+        lens = torch.empty(B, dtype=torch.int32, device=dev)
+        check(lib().nr_gru_fwd_f32(_p(x), _p(mask), _p(w_ih), _p(w_hh), _p(b_ih), _p(b_hh), B, L, Din, H, _p(gi), _p(gh), _p(hall),
+                                   _p(gates), _p(lens), _stream()), "nr_gru_fwd_f32")
+        if train:
+            ctx.save_for_backward(x, w_ih, w_hh, hall, gates, lens)
+        return hall[L].clone()
+
+    @staticmethod
+    def backward(ctx, g):
+        x, w_ih, w_hh, hall, gates, lens = ctx.saved_tensors
+        B, L, Din = x.shape
+        H = w_hh.shape[1]
+        g = _f32(g, "grad")
+        dev = g.device
+        dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        dw_ih, dw_hh = torch.empty_like(w_ih), torch.empty_like(w_hh)
+        db_ih = torch.empty(3 * H, dtype=torch.float32, device=dev)
+        db_hh = torch.empty(3 * H, dtype=torch.float32, device=dev)
+        Lb = lib()
+        ws = _ws(Lb.nr_gru_bwd_ws_bytes(B, L, Din, H), dev)
+        check(Lb.nr_gru_bwd_f32(_p(g), _p(x), _p(w_ih), _p(w_hh), B, L, Din, H, _p(hall), _p(gates), _p(lens), _p(dx), _p(dw_ih),
+                                _p(dw_hh), _p(db_ih), _p(db_hh), _p(ws), ws.numel() * 4, _stream()), "nr_gru_bwd_f32")
+        return dx, None, dw_ih, dw_hh, db_ih, db_hh
+
+
+def gru_final_state(x, mask, w_ih, w_hh, b_ih, b_hh):
+    """x [B,L,Din], mask [B,L] (1 = clicked news present, at least one per row) -> [B,H]"""
+    x, mask = _f32(x, "news_embedding"), _i64(mask, "his_mask")
+    if x.dim() != 3 or mask.shape != x.shape[:2]:
+        raise NewsrecError(f"gru_final_state: x {tuple(x.shape)} / mask {tuple(mask.shape)} shape mismatch")
+    return _GRUFinal.apply(x, mask, _f32(w_ih, "rnn.weight_ih_l0"), _f32(w_hh, "rnn.weight_hh_l0"), _f32(b_ih, "rnn.bias_ih_l0"),
+                           _f32(b_hh, "rnn.bias_hh_l0"))
+
+
 # ----------------------------------------------------------------------------- BERT embedding stage
 def colsum(x2d):
     """deterministic column sums of a [R,N] matrix -> [N]"""

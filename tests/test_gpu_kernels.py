@@ -77,7 +77,8 @@ def test_linear_forward(ops, R, K, N, act):
 
 
 @pytest.mark.parametrize("R,K,N", [(1760 * 4, 300, 900), (3200, 1200, 300), (1600, 300, 1200), (200, 24, 24), (77, 20, 36),
-                                   (64, 25, 10)])
+                                   (64, 25, 10), (10000, 96, 288),      # tall dW tile, ragged K, empty split-K slices
+                                   (56320 // 4 + 20, 300, 300)])
 def test_linear_backward(ops, R, K, N):
     g = G(4)
     x = torch.randn(R, K, generator=g)
@@ -374,3 +375,47 @@ def test_adam_matches_torch(ops):
         ops.adam_step(pg, grad.cuda(), m, v, step, 1e-3)
     assert relerr(pg, pr) < 1e-6
     assert relerr(m, opt.state[pr]["exp_avg"]) < 1e-6 and relerr(v, opt.state[pr]["exp_avg_sq"]) < 1e-6
+
+
+# ------------------------------------------------------------------ GRU user encoder (final state of a packed batch)
+@pytest.mark.parametrize("B,L,D", [(32, 50, 300), (8, 50, 768), (5, 7, 24), (200, 50, 96), (1, 1, 8)])
+def test_gru_final_state(ops, B, L, D):
+    """vs the oracle's explicit cell loop AND torch.nn.GRU over pack_padded_sequence on CPU (the reference's
+    call, encoder.py:226-232): user vector, input gradient and the four parameter gradients."""
+    g = G(31)
+    x = torch.randn(B, L, D, generator=g)
+    lens = torch.randint(1, L + 1, (B,), generator=g)
+    lens[0] = 1
+    if B > 1:
+        lens[1] = L
+    mask = (torch.arange(L)[None] < lens[:, None]).long()
+    rnn = torch.nn.GRU(D, D, batch_first=True)
+    for n_, p_ in rnn.named_parameters():
+        if "weight" in n_:
+            torch.nn.init.orthogonal_(p_)
+        else:
+            with torch.no_grad():
+                p_.copy_(0.1 * torch.randn(p_.shape, generator=g))
+    dy = torch.randn(B, D, generator=g)
+    # torch reference (CPU)
+    xr = x.clone().requires_grad_(True)
+    packed = torch.nn.utils.rnn.pack_padded_sequence(xr, lens, batch_first=True, enforce_sorted=False)
+    _, h = rnn(packed)
+    h = h.transpose(0, 1).squeeze(1)
+    h.backward(dy)
+    # oracle restatement agrees with torch
+    P = {"userEncoder.rnn." + k: v.detach() for k, v in rnn.state_dict().items()}
+    assert relerr(O.rnn_user_encoder(P, x, mask).squeeze(1), h) < 2e-6
+    # HIP path
+    W = {k: v.detach().clone().cuda().requires_grad_(True) for k, v in rnn.state_dict().items()}
+    xg = x.cuda().requires_grad_(True)
+    out = ops.gru_final_state(xg, mask.cuda(), W["weight_ih_l0"], W["weight_hh_l0"], W["bias_ih_l0"], W["bias_hh_l0"])
+    assert relerr(out, h) < FP32_TOL
+    out.backward(dy.cuda())
+    assert relerr(xg.grad, xr.grad) < 5e-5
+    for k, p_ in rnn.named_parameters():
+        assert relerr(W[k].grad, p_.grad) < 5e-5, k
+    # eval call (nothing saved) gives the same state
+    with torch.no_grad():
+        assert torch.equal(ops.gru_final_state(x.cuda(), mask.cuda(), W["weight_ih_l0"], W["weight_hh_l0"], W["bias_ih_l0"],
+                                               W["bias_hh_l0"]), out.detach())
