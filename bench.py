@@ -60,17 +60,26 @@ def synth_train_batch(g, B, Nn, ids, msk):
                 his_token_id=ids[his_idx], his_attn_mask=msk[his_idx], label=torch.zeros(B, dtype=torch.int64))
 
 
-def build_model(device):
+WORKLOADS = {   # name: (news encoder, user encoder, embedding dim, hidden dim, description)
+    "nrms": ("tfm", "tfm", 300, 300, "configs[1]: NRMS-style MHSA news+user encoder (TwoTower-Tfm-Tfm), T=32, L=50, K=4, 300-d, 12 heads"),
+    "cnn_rnn": ("cnn", "rnn", 768, 768, "configs[0] shape on the GPU: main.twotower defaults (TwoTower-Cnn-Rnn), 768-d"),
+    "bert": ("bert", "attn", 768, 768, "configs[4] shape on one GPU: BERT-base news encoder (12 layers, 768-d) + attention user encoder, fp32"),
+}
+
+
+def build_model(device, workload="nrms"):
     import types
     from models.TwoTower import TwoTowerModel
     from models.modules import encoder as Enc
+    ne, ue, E, D, _ = WORKLOADS[workload]
     mgr = types.SimpleNamespace(
         plm_dim=E, hidden_dim=D, head_num=H, his_size=L, sequence_length=T, negative_num=K, vocab_size=V, device=device,
         learning_rate=1e-5, rank=0, world_size=1, verbose=None, enable_fields=["title"], dropout_p=0.1, synthetic_plm=True,
         plm_dir="", distributed=False, debug=False, impr_size=20, batch_size_eval=200, scheduler="none", epochs=1, warmup=0.1)
     torch.manual_seed(3407)
-    model = TwoTowerModel(mgr, Enc.TfmNewsEncoder(mgr), Enc.TfmUserEncoder(mgr))
-    return model, mgr
+    news = {"tfm": Enc.TfmNewsEncoder, "cnn": Enc.CnnNewsEncoder, "bert": Enc.AllBertNewsEncoder}[ne](mgr)
+    user = {"tfm": Enc.TfmUserEncoder, "rnn": Enc.RnnUserEncoder, "attn": Enc.AttnUserEncoder}[ue](mgr)
+    return TwoTowerModel(mgr, news, user), mgr
 
 
 def train_flops_per_impression():
@@ -187,6 +196,9 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch-size", type=int, default=32, help="impressions per GPU per step (reference -bs default)")
+    ap.add_argument("--workload", choices=sorted(WORKLOADS), default="nrms",
+                    help="nrms = the headline workload (BASELINE configs[1]); the others are extra measurements "
+                         "(no roofline/cpu_baseline/eval legs)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-eval", action="store_true")
     args = ap.parse_args()
@@ -203,7 +215,10 @@ def main():
     from newsrec_hip import ops
 
     B = args.batch_size
-    model, mgr = build_model(local)
+    extra = args.workload != "nrms"
+    if extra:
+        args.no_eval = args.no_cpu_baseline = True
+    model, mgr = build_model(local, args.workload)
     model = model.cuda().train()
     net = model
     if world > 1:
@@ -270,18 +285,17 @@ def main():
             gbs = f["work_per_step"] / (f["ms_per_step"] * 1e-3) / 1e9
             hbm_step[name] = {"GB/s": round(gbs, 1), "frac_of_8TBs": round(gbs / PEAK_HBM_GBS, 4), "ms_per_step": f["ms_per_step"]}
     with torch.no_grad():
-        hbm = hbm_kernel_leg(model, B)
+        hbm = hbm_kernel_leg(model, B) if not extra else {}
 
     out = {
         "metric": "train impressions/sec (node), NRMS-shape MIND-large; eval impressions/sec",
         "value": round(value, 2), "unit": "impressions/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
-        "config": {"workload": "configs[1]: NRMS-style MHSA news+user encoder (TwoTower-Tfm-Tfm), T=32, L=50, K=4, 300-d, "
-                               "12 heads, train step = fwd+bwd+Adam with dropout 0.1",
+        "config": {"workload": WORKLOADS[args.workload][4] + ", train step = fwd+bwd+Adam with dropout 0.1",
                    "per_gpu_batch": B, "global_batch": B * world, "vocab": V, "parallelism": f"dp{world}"},
         "loss": round(final_loss, 5),
-        "model_tflops": round(value * train_flops_per_impression() / 1e12, 2),
+        "model_tflops": round(value * train_flops_per_impression() / 1e12, 2) if not extra else None,
         "roofline": roofline, "hbm_kernels": hbm, "hbm_families_in_step": hbm_step, "kernel_ms_per_step": {k: v["ms_per_step"] for k, v in fam.items()},
     }
 

@@ -55,8 +55,11 @@ struct LoaderKC {
     const float* ptr[ROWS / 32];   // &base[row*ld + c4]
     unsigned valid, first, last;   // per pass i, bit i: row valid / conv t==0 / conv t==T-1
     int c4;
-    __device__ __forceinline__ void init(const float* base, int64_t ld, int row0, int nrows, int tid, int convT) {
+    const float* safe;             // a readable address for predicated-off lanes (loads stay unconditional: a
+                                   // branch around every load costs more than the wasted 16 bytes)
+    __device__ __forceinline__ void init(const float* base, int64_t ld, int row0, int nrows, int tid, int convT, const float* safe_) {
         c4 = (tid & 7) * 4;
+        safe = safe_;
         const int r0 = tid >> 3;
         valid = first = last = 0;
 #pragma unroll
@@ -87,7 +90,8 @@ struct LoaderKC {
             bool ok = kok && ((valid >> i) & 1u);
             if (((first >> i) & 1u) && seg0) ok = false;
             if (((last >> i) & 1u) && seg2) ok = false;
-            reg[i] = ok ? *reinterpret_cast<const float4*>(ptr[i] + k0) : make_float4(0.f, 0.f, 0.f, 0.f);
+            const float4 v = *reinterpret_cast<const float4*>(ok ? ptr[i] + k0 : safe);
+            reg[i] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
         }
     }
 };
@@ -111,8 +115,9 @@ struct LoaderRM {
     uint32_t off[NV];                        // byte offset of element i inside a k-tile: (kr*ld + column) * 4, column clamped
     unsigned cvalid;                         // bit i: column in range
     int col0, convE;
-    __device__ __forceinline__ void init(const float* base_, int64_t ld_, int col0_, int ncols, int tid, int convE_) {
-        base = base_; ld = ld_; col0 = col0_; convE = convE_;
+    const float* safe;
+    __device__ __forceinline__ void init(const float* base_, int64_t ld_, int col0_, int ncols, int tid, int convE_, const float* safe_) {
+        base = base_; ld = ld_; col0 = col0_; convE = convE_; safe = safe_;
         cvalid = 0;
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
@@ -138,7 +143,8 @@ struct LoaderRM {
                 const int t = k % convT;
                 if ((t == 0 && c < convE) || (t == convT - 1 && c >= 2 * convE)) ok = false;
             }
-            reg[i] = ok ? *reinterpret_cast<const float4*>(kb + off[i]) : make_float4(0.f, 0.f, 0.f, 0.f);
+            const float4 v = *reinterpret_cast<const float4*>(ok ? kb + off[i] : reinterpret_cast<const char*>(safe));
+            reg[i] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
         }
     }
 };
@@ -295,8 +301,11 @@ __global__ __launch_bounds__(256, (WM * NJ <= 2) ? 4 : (WM * NJ <= 4 ? 3 : 2)) v
     const int convA = (p.conv_on == 1) ? p.conv_T : 0;
     const int convB = (p.conv_on == 2) ? p.conv_T : 0;
     LoaderKC<BM> lkA; LoaderRM<BM> lrA; LoaderKC<BN> lkB; LoaderRM<BN> lrB;
-    if (A_KC) lkA.init(p.A, p.lda, m0, p.M, tid, convA); else lrA.init(p.A, p.lda, m0, p.M, tid, 0);
-    if (B_KC) lkB.init(p.B, p.ldb, n0, p.N, tid, 0);     else lrB.init(p.B, p.ldb, n0, p.N, tid, convB ? p.conv_E : 0);
+    // conv views start one token row (conv_E floats) before the tensor: base + conv_E is the first readable float
+    const float* safeA = p.A + (convA ? p.conv_E : 0);
+    const float* safeB = p.B + (convB ? p.conv_E : 0);
+    if (A_KC) lkA.init(p.A, p.lda, m0, p.M, tid, convA, safeA); else lrA.init(p.A, p.lda, m0, p.M, tid, 0, safeA);
+    if (B_KC) lkB.init(p.B, p.ldb, n0, p.N, tid, 0, safeB);     else lrB.init(p.B, p.ldb, n0, p.N, tid, convB ? p.conv_E : 0, safeB);
 
     // Full k-tiles of a non-conv GEMM load unconditionally: rows/columns past the edge read a clamped
     // (valid) address and only ever reach output elements that are not stored.
