@@ -173,7 +173,8 @@ int nr_tfm_layer_bwd_f32(const float* dy, const float* x, const int64_t* mask, i
  * gate order r|z|n.  Caller-allocated: gi [B*L,3H], gh [B,3H] scratch, hall [(L+1),B,H] (hall[0] is zeroed
  * here), gates [L,B,4H] (r,z,n,gh_n; NULL = eval, nothing saved), lens [B] int32.  No host sync
  * (the reference's lens.cpu() at encoder.py:227 is gone). */
-int nr_gru_fwd_f32(const float* x, const int64_t* mask, const float* w_ih, const float* w_hh, const float* b_ih, const float* b_hh, int64_t B, int64_t L, int64_t Din, int64_t H, float* gi, float* gh, float* hall, float* gates, int32_t* lens, void* stream);
+size_t nr_gru_fwd_ws_bytes(int64_t B, int64_t H);   /* split-K scratch of the per-step h W_hh^T GEMM (32 sequences alone fill 1/8 of the CUs) */
+int nr_gru_fwd_f32(const float* x, const int64_t* mask, const float* w_ih, const float* w_hh, const float* b_ih, const float* b_hh, int64_t B, int64_t L, int64_t Din, int64_t H, float* gi, float* gh, float* hall, float* gates, int32_t* lens, void* ws, size_t ws_bytes, void* stream);
 /* dh_out [B,H] = gradient of hall[L]; dx [B*L,Din] may be NULL; dw_ih, dw_hh, db_ih, db_hh are overwritten. */
 size_t nr_gru_bwd_ws_bytes(int64_t B, int64_t L, int64_t Din, int64_t H);
 int nr_gru_bwd_f32(const float* dh_out, const float* x, const float* w_ih, const float* w_hh, int64_t B, int64_t L, int64_t Din, int64_t H, const float* hall, const float* gates, const int32_t* lens, float* dx, float* dw_ih, float* dw_hh, float* db_ih, float* db_hh, void* ws, size_t ws_bytes, void* stream);

@@ -76,20 +76,32 @@ static inline float* bump(char*& cur, size_t floats) {
 static inline size_t pad256(size_t floats) { return ((floats * sizeof(float) + 255) / 256) * 256; }
 
 // y = act(x w^T + b)
+// skinny problems (a GRU step: 32 sequences) leave most CUs idle unless the reduction is split: with a
+// workspace of skinny_ws_bytes() the GEMM runs split-K + the deterministic slab reduce
+static size_t skinny_ws_bytes(int64_t M, int64_t N, int64_t K) {
+    return gemm_workspace_bytes((int)M, (int)N, choose_ksplit((int)M, (int)N, (int)K)) + 256;
+}
+static void maybe_split(GemmParams& p, float* ws, size_t ws_bytes) {
+    if (!ws) return;
+    const int ks = choose_ksplit(p.M, p.N, p.K);
+    if (ks > 1 && gemm_workspace_bytes(p.M, p.N, ks) <= ws_bytes) p.ksplit = ks;
+}
 static int linear_fwd(const float* x, int64_t ldx, const float* w, const float* b, int64_t R, int64_t K, int64_t N, int epi,
-                      float* y, float* z, hipStream_t s) {
+                      float* y, float* z, hipStream_t s, float* ws = nullptr, size_t ws_bytes = 0) {
     GemmParams p;
     p.A = x; p.lda = ldx; p.B = w; p.ldb = K; p.C = y; p.ldc = N;
     p.M = (int)R; p.N = (int)N; p.K = (int)K; p.bias = b; p.epi = epi; p.out2 = z; p.ldout2 = N;
-    return gemm_f32(p, true, true, nullptr, 0, s);
+    maybe_split(p, ws, ws_bytes);
+    return gemm_f32(p, true, true, ws, ws_bytes, s);
 }
 // dx = dy w  (+ epilogue)
 static int linear_bwd_input(const float* dy, int64_t lddy, const float* w, int64_t R, int64_t N, int64_t K, int epi,
-                            const float* aux, const float* aux2, float* dx, hipStream_t s) {
+                            const float* aux, const float* aux2, float* dx, hipStream_t s, float* ws = nullptr, size_t ws_bytes = 0) {
     GemmParams p;
     p.A = dy; p.lda = lddy; p.B = w; p.ldb = K; p.C = dx; p.ldc = K;
     p.M = (int)R; p.N = (int)K; p.K = (int)N; p.epi = epi; p.aux = aux; p.ldaux = K; p.aux2 = aux2; p.ldaux2 = K;
-    return gemm_f32(p, true, false, nullptr, 0, s);
+    maybe_split(p, ws, ws_bytes);
+    return gemm_f32(p, true, false, ws, ws_bytes, s);
 }
 static size_t bwd_weight_ws(int64_t R, int64_t N, int64_t K, bool with_bias) {
     const int ks = choose_ksplit((int)N, (int)K, (int)R);
@@ -503,7 +515,7 @@ int nr_tfm_layer_bwd_f32(const float* dy, const float* x, const int64_t* mask, i
 // ------------------------------------------------------------------------------------ GRU user encoder
 int nr_gru_fwd_f32(const float* x, const int64_t* mask, const float* w_ih, const float* w_hh, const float* b_ih, const float* b_hh,
                    int64_t B, int64_t L, int64_t Din, int64_t H, float* gi, float* gh, float* hall, float* gates, int32_t* lens,
-                   void* stream) {
+                   void* ws, size_t ws_bytes, void* stream) {
     NR_CHECK_ARG(B >= 0 && L > 0 && Din > 0 && H > 0, "gru_fwd: bad sizes");
     if (B == 0) return NR_OK;
     NR_CHECK_ARG(x && mask && w_ih && w_hh && b_ih && b_hh && gi && gh && hall && lens, "gru_fwd: null pointer");
@@ -514,16 +526,18 @@ int nr_gru_fwd_f32(const float* x, const int64_t* mask, const float* w_ih, const
     if (int rc = linear_fwd(x, Din, w_ih, b_ih, B * L, Din, 3 * H, EPI_NONE, gi, nullptr, s)) return rc;
     for (int t = 0; t < (int)L; ++t) {
         const float* hp = hall + (size_t)t * B * H;
-        if (int rc = linear_fwd(hp, H, w_hh, b_hh, B, H, 3 * H, EPI_NONE, gh, nullptr, s)) return rc;
+        if (int rc = linear_fwd(hp, H, w_hh, b_hh, B, H, 3 * H, EPI_NONE, gh, nullptr, s, (float*)ws, ws_bytes)) return rc;
         if (int rc = gru_gate_fwd(gi, gh, hp, lens, hall + (size_t)(t + 1) * B * H, gates ? gates + (size_t)t * B * 4 * H : nullptr,
                                   (int)B, (int)L, (int)H, t, s)) return rc;
     }
     return NR_OK;
 }
 
+size_t nr_gru_fwd_ws_bytes(int64_t B, int64_t H) { return skinny_ws_bytes(B, 3 * H, H); }
+
 size_t nr_gru_bwd_ws_bytes(int64_t B, int64_t L, int64_t Din, int64_t H) {
     return 2 * pad256((size_t)B * L * 3 * H) + 3 * pad256((size_t)B * H) +
-           std::max(bwd_weight_ws(B * L, 3 * H, H, true), bwd_weight_ws(B * L, 3 * H, Din, true)) + 1024;
+           std::max(std::max(bwd_weight_ws(B * L, 3 * H, H, true), bwd_weight_ws(B * L, 3 * H, Din, true)), skinny_ws_bytes(B, H, 3 * H)) + 1024;
 }
 
 int nr_gru_bwd_f32(const float* dh_out, const float* x, const float* w_ih, const float* w_hh, int64_t B, int64_t L, int64_t Din,
@@ -546,7 +560,7 @@ int nr_gru_bwd_f32(const float* dh_out, const float* x, const float* w_ih, const
         if (int rc = gru_gate_bwd(dh, gates + (size_t)t * B * 4 * H, hall + (size_t)t * B * H, lens, dgi, dgh_t, direct, (int)B,
                                   (int)L, (int)H, t, s)) return rc;
         // dh_{t-1} = dh_t * z  +  dGH_t W_hh
-        if (int rc = linear_bwd_input(dgh_t, 3 * H, w_hh, B, 3 * H, H, EPI_ADD_AUX, direct, nullptr, pp[k], s)) return rc;
+        if (int rc = linear_bwd_input(dgh_t, 3 * H, w_hh, B, 3 * H, H, EPI_ADD_AUX, direct, nullptr, pp[k], s, (float*)cur, rest)) return rc;
         dh = pp[k];
         k ^= 1;
     }

@@ -298,8 +298,9 @@ class _GRUFinal(torch.autograd.Function):
         hall = torch.empty(L + 1, B, H, dtype=torch.float32, device=dev)
         gates = torch.empty(L, B, 4 * H, dtype=torch.float32, device=dev) if train else None
         lens = torch.empty(B, dtype=torch.int32, device=dev)
+        ws = _ws(lib().nr_gru_fwd_ws_bytes(B, H), dev)
         check(lib().nr_gru_fwd_f32(_p(x), _p(mask), _p(w_ih), _p(w_hh), _p(b_ih), _p(b_hh), B, L, Din, H, _p(gi), _p(gh), _p(hall),
-                                   _p(gates), _p(lens), _stream()), "nr_gru_fwd_f32")
+                                   _p(gates), _p(lens), _p(ws), ws.numel() * 4, _stream()), "nr_gru_fwd_f32")
         if train:
             ctx.save_for_backward(x, w_ih, w_hh, hall, gates, lens)
         return hall[L].clone()
