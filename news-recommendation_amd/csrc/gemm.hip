@@ -253,7 +253,7 @@ __device__ __forceinline__ void store_block(const f32x16 (&acc)[WM][NJ], float* 
 }
 
 template <bool A_KC, bool B_KC, int WM, int NJ>
-__global__ __launch_bounds__(256, (WM * NJ <= 2) ? 4 : (WM * NJ <= 4 ? 3 : 2)) void gemm_f32_kernel(const GemmParams p) {
+__global__ __launch_bounds__(256, (WM * NJ <= 2) ? 4 : 2) void gemm_f32_kernel(const GemmParams p) {
     constexpr int BM = 64 * WM, BN = 64 * NJ;
     constexpr int A_ELEMS = A_KC ? BM * KC_LD : BK * RedMajor<BM>::LD;
     constexpr int NVA = 8 * BM / 256, NVB = 8 * BN / 256;     // float4 per thread per k-tile
