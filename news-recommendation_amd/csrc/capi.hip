@@ -106,7 +106,7 @@ static int linear_bwd_input(const float* dy, int64_t lddy, const float* w, int64
 static size_t bwd_weight_ws(int64_t R, int64_t N, int64_t K, bool with_bias) {
     const int ks = choose_ksplit((int)N, (int)K, (int)R);
     size_t b = pad256(gemm_workspace_bytes((int)N, (int)K, ks) / sizeof(float));
-    if (with_bias) b += pad256((size_t)colsum_chunks(R) * N);
+    if (with_bias) b += pad256(std::max((size_t)colsum_chunks(R), (size_t)ks) * N);
     return b;
 }
 // dw = dy^T x ; db = colsum(dy)
@@ -125,12 +125,13 @@ static int linear_bwd_weight(const float* dy, int64_t lddy, const float* x, int6
     if (conv_T > 0) { p.conv_on = 2; p.conv_T = conv_T; p.conv_E = conv_E; }
     const size_t slab_floats = gemm_workspace_bytes((int)N, (int)K, p.ksplit) / sizeof(float);
     float* slabs = bump(cur, slab_floats);
+    float* part = db ? bump(cur, std::max((size_t)colsum_chunks(R), (size_t)p.ksplit) * N) : nullptr;
+    // the bias gradient db = colsum(dy) rides on the GEMM (dy tiles are in LDS anyway) unless the slow path runs
+    const bool fused = db && gemm_fast_path(p, false, false);
+    if (fused) { p.csum = db; p.csum_part = part; }
     int rc = gemm_f32(p, false, false, slabs, slab_floats * sizeof(float), s);
     if (rc != NR_OK) return rc;
-    if (db) {
-        float* part = bump(cur, (size_t)colsum_chunks(R) * N);
-        rc = colsum(dy, lddy, R, (int)N, db, part, s);
-    }
+    if (db && !fused) rc = colsum(dy, lddy, R, (int)N, db, part, s);
     return rc;
 }
 

@@ -32,10 +32,15 @@ struct GemmParams {
     int conv_T = 0, conv_E = 0;
     int ksplit = 1;
     int64_t split_stride = 0;
+    // reduction-major A only (dW = dY^T X): also emit csum[m] = sum_k A(m,k) — the bias gradient — from the
+    // tiles already in LDS; csum_part [ksplit, M] is scratch for the split-K case
+    float* csum = nullptr;
+    float* csum_part = nullptr;
 };
 
 int gemm_f32(GemmParams p, bool a_kc, bool b_kc, float* workspace, size_t ws_bytes, hipStream_t s);
 size_t gemm_workspace_bytes(int M, int N, int ksplit);
 int choose_ksplit(int M, int N, int K);
+bool gemm_fast_path(const GemmParams& p, bool a_kc, bool b_kc);
 
 }  // namespace nr

@@ -364,6 +364,26 @@ __global__ __launch_bounds__(256, (WM * NJ <= 2) ? 4 : 2) void gemm_f32_kernel(c
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a[i][e], f.b[j][e], acc[i][j], 0, 0, 0);
     };
 
+    // bias gradient riding on the dW GEMM: the n-tile-0 workgroups also sum their A tile over k
+    constexpr int NCS = (BM + 255) / 256;
+    float cs[NCS];
+#pragma unroll
+    for (int j = 0; j < NCS; ++j) cs[j] = 0.f;
+    const bool do_csum = !A_KC && p.csum != nullptr && tn == 0;
+    auto csum_tile = [&]() {
+        if (A_KC) return;
+#pragma unroll
+        for (int j = 0; j < NCS; ++j) {
+            const int c = tid + 256 * j;
+            if (c < BM) {
+                float a = 0.f;
+#pragma unroll 8
+                for (int k = 0; k < BK; ++k) a += As[k * RedMajor<BM>::LD + c];
+                cs[j] += a;
+            }
+        }
+    };
+
     // tiles [kt_begin, kt_full) are complete (4 quads); at most one ragged tile follows
     const int kt_full = min(kt_end, p.K / BK);
     if (kt_begin < kt_end) {
@@ -392,6 +412,7 @@ __global__ __launch_bounds__(256, (WM * NJ <= 2) ? 4 : 2) void gemm_f32_kernel(c
         __builtin_amdgcn_sched_barrier(0);
         fmma(f0);
         fmma(f1);
+        if (do_csum) csum_tile();
         __syncthreads();                     // everyone is done reading the single buffer
         if (more) lstore();
         __syncthreads();
@@ -402,6 +423,15 @@ __global__ __launch_bounds__(256, (WM * NJ <= 2) ? 4 : 2) void gemm_f32_kernel(c
             Frags f;
             fload(f, kq);
             fmma(f);
+        }
+        if (do_csum) csum_tile();            // rows k >= K of the tile were zero-filled by the loader
+    }
+    if (do_csum) {
+        float* dst = p.ksplit > 1 ? p.csum_part + (int64_t)ks * p.M : p.csum;
+#pragma unroll
+        for (int j = 0; j < NCS; ++j) {
+            const int c = tid + 256 * j;
+            if (c < BM && m0 + c < p.M) dst[m0 + c] = cs[j];
         }
     }
 
@@ -437,6 +467,13 @@ __global__ __launch_bounds__(256, (WM * NJ <= 2) ? 4 : 2) void gemm_f32_kernel(c
 // sum split-K slabs (fixed order -> deterministic), add bias, apply epilogue
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmParams p, const float* __restrict__ slabs) {
     const int64_t total = (int64_t)p.M * p.N;
+    if (p.csum) {
+        for (int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; m < p.M; m += (int64_t)gridDim.x * blockDim.x) {
+            float v = 0.f;
+            for (int s = 0; s < p.ksplit; ++s) v += p.csum_part[(int64_t)s * p.M + m];
+            p.csum[m] = v;
+        }
+    }
     for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
          idx += (int64_t)gridDim.x * blockDim.x) {
         const int m = (int)(idx / p.N), n = (int)(idx - (int64_t)m * p.N);
@@ -499,16 +536,22 @@ int choose_ksplit(int M, int N, int K) {
     return std::max(ks, 1);
 }
 
-int gemm_f32(GemmParams p, bool a_kc, bool b_kc, float* workspace, size_t ws_bytes, hipStream_t s) {
-    NR_CHECK_ARG(p.M >= 0 && p.N >= 0 && p.K >= 0, "gemm: negative dims");
-    if (p.M == 0 || p.N == 0) return NR_OK;
-    NR_CHECK_ARG(p.A && p.B && p.C, "gemm: null operand");
-    if (p.ksplit < 1) p.ksplit = 1;
+bool gemm_fast_path(const GemmParams& p, bool a_kc, bool b_kc) {
     // vector (16 B) loads need 4-float alignment of every row start and of the contiguous extent
     auto al = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
     bool fast = al(p.A) && al(p.B) && (p.lda % 4 == 0) && (p.ldb % 4 == 0);
     fast = fast && (a_kc ? (p.K % 4 == 0) : (p.M % 4 == 0)) && (b_kc ? (p.K % 4 == 0) : (p.N % 4 == 0));
     if (p.conv_on) fast = fast && (p.conv_E % 4 == 0);
+    return fast && !(!a_kc && b_kc);
+}
+
+int gemm_f32(GemmParams p, bool a_kc, bool b_kc, float* workspace, size_t ws_bytes, hipStream_t s) {
+    NR_CHECK_ARG(p.M >= 0 && p.N >= 0 && p.K >= 0, "gemm: negative dims");
+    if (p.M == 0 || p.N == 0) return NR_OK;
+    NR_CHECK_ARG(p.A && p.B && p.C, "gemm: null operand");
+    if (p.ksplit < 1) p.ksplit = 1;
+    const bool fast = gemm_fast_path(p, a_kc, b_kc);
+    if (p.csum) NR_CHECK_ARG(fast && !a_kc && (p.ksplit <= 1 || p.csum_part), "gemm: fused column sums need the tiled reduction-major path");
     ProfScope prof(FAM_GEMM, s, 2.0 * p.M * p.N * p.K);
     if (!fast) {
         p.ksplit = 1;
