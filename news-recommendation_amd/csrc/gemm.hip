@@ -520,19 +520,28 @@ static int launch_tiled(const GemmParams& p, hipStream_t s) {
 
 // dW GEMMs (both operands reduction-major, split-K): the tall 320-row tile when it pads M less than 128-row tiles
 // (only for long reductions: with few k-tiles per split its 80 MFMAs per wave and k-tile serialise on too few CUs)
-static bool tall_tile(int M, int K) { return K >= 8192 && cdiv(M, 320) * 320 < cdiv(M, 128) * 128; }
+// and many n-tiles to share the tall A tile through L2: measured on the NRMS shapes it wins for dW[300,1200]
+// (85 vs 79 TF/s) and loses for dW[900,300] / dW[300,300] (74 vs 78, 51 vs 59)
+static bool tall_tile(int M, int N, int K) { return K >= 8192 && N >= 1024 && cdiv(M, 320) * 320 < cdiv(M, 128) * 128; }
 
 size_t gemm_workspace_bytes(int M, int N, int ksplit) {
     return ksplit > 1 ? (size_t)ksplit * M * N * sizeof(float) : 0;
 }
 
 int choose_ksplit(int M, int N, int K) {
-    // fill ~2 waves of 256 CUs when the output grid alone cannot (dW GEMMs: tiny MxN, huge K)
-    const int tiles = cdiv(M, tall_tile(M, K) ? 320 : 128) * cdiv(N, 64);
+    // dW GEMMs: tiny MxN, huge K.  Two pulls (swept on MI355X, tools/dw_lab.sh): enough workgroups to fill the
+    // chip (>= 512), and slices of ~32 k-tiles — shorter slices than the fill needs only add slab traffic, longer
+    // ones leave the single-buffered loop latency-bound (dW[1200,300]: 68 TF/s at 512 workgroups, 85 at 2048+)
+    const int tiles = cdiv(M, tall_tile(M, N, K) ? 320 : 128) * cdiv(N, 64);
     const int kt = cdiv(K, BK);
-    if (tiles >= 256 || kt < 8) return 1;
-    int ks = (512 + tiles - 1) / tiles;
-    ks = std::min(ks, kt / 4);
+    if (tiles >= 2048 || kt < 8) return 1;   // (288 tiles on 256 CUs would run as two unbalanced rounds: keep splitting)
+    int ks = std::max((512 + tiles - 1) / tiles, kt / 32);
+    ks = std::min(ks, std::max(1, 3072 / tiles));
+    ks = std::max(std::min(ks, kt / 4), 1);
+    // an even slice length (32 k-tiles = 1024 rows) starts every slice a multiple of 16 KiB apart: all of them
+    // stream through the same L2 channels (dW[300,1200]: 75 TF/s at 32 tiles per slice, 85 at 33)
+    int per = cdiv(kt, ks);
+    if (ks > 1 && per % 2 == 0) ks = cdiv(kt, per + 1);
     return std::max(ks, 1);
 }
 
@@ -582,7 +591,7 @@ int gemm_f32(GemmParams p, bool a_kc, bool b_kc, float* workspace, size_t ws_byt
     if (a_kc && b_kc)        rc = small ? launch_tiled<true, true, 1, 1>(q, s) : wide ? launch_tiled<true, true, 2, 2>(q, s) : launch_tiled<true, true, 2, 1>(q, s);
     else if (a_kc && !b_kc)  rc = small ? launch_tiled<true, false, 1, 1>(q, s) : wide ? launch_tiled<true, false, 2, 2>(q, s) : launch_tiled<true, false, 2, 1>(q, s);
     else if (!a_kc && !b_kc) {
-        if (!p.conv_on && !wide && (p.epi == EPI_NONE || p.ksplit > 1) && tall_tile(p.M, p.K)) rc = launch_tiled<false, false, 5, 1>(q, s);
+        if (!p.conv_on && !wide && (p.epi == EPI_NONE || p.ksplit > 1) && tall_tile(p.M, p.N, p.K)) rc = launch_tiled<false, false, 5, 1>(q, s);
         else rc = wide ? launch_tiled<false, false, 2, 2>(q, s) : launch_tiled<false, false, 2, 1>(q, s);
     }
     else { set_error("gemm: layout (A red-major, B k-contig) not built"); return NR_ERR_UNSUPPORTED; }
