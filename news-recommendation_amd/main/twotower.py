@@ -22,6 +22,9 @@ def main(rank, manager):
         raise ValueError(f"unknown encoder pair -ne {manager.newsEncoder} -ue {manager.userEncoder}")
     model = TwoTowerModel(manager, NEWS_ENCODERS[manager.newsEncoder](manager), USER_ENCODERS[manager.userEncoder](manager))
     model = model.to(manager.device)
+    if "train" in loaders and not loaders["train"].dataset.ship_tokens:
+        ds = loaders["train"].dataset           # token rows are gathered on the device from these resident tables
+        model.attach_news_tokens(ds.token_ids, ds.attn_masks)
     if manager.mode == "train":
         if manager.world_size > 1:
             # gradient buckets are views of the flat all-reduce buffers: the dense V x E table gradient

@@ -130,10 +130,27 @@ class TwoTowerBaseModel(BaseModel):
         """[B,C,D] x [B,1,D] -> [B,C] dot products / sqrt(D) (reference BaseModel.py:164-175)."""
         return ops.score(cdd_news_repr, user_repr)
 
+    # ------------------------------------------------------------------ device-side batch assembly (SURVEY §8 f1)
+    def attach_news_tokens(self, token_ids, attn_masks):
+        """keep the corpus' [Nn,T] token-id / mask tables in HBM; batches that carry only news indices
+        (datasets built without --host-assembly) are then assembled by a row gather on the device — the
+        same rows the reference's MIND.__getitem__ picks with numpy (utils/dataset.py:152-155)."""
+        as_t = lambda a: a if isinstance(a, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(a))
+        self._news_token_ids = as_t(token_ids).to(self.device).long().contiguous()
+        self._news_attn_masks = as_t(attn_masks).to(self.device).long().contiguous()
+
+    def _tokens(self, x, key):
+        """(token_id, attn_mask) of the `key` ("cdd" | "his") titles of a batch, on the device"""
+        if key + "_token_id" in x:
+            return x[key + "_token_id"].to(self.device), x[key + "_attn_mask"].to(self.device)
+        if getattr(self, "_news_token_ids", None) is None:
+            raise RuntimeError("the batch carries no token ids and no token table is attached: call "
+                               "model.attach_news_tokens(dataset.token_ids, dataset.attn_masks) or use --host-assembly")
+        idx = x[key + "_idx"].to(self.device)
+        return ops.gather_rows_i64(self._news_token_ids, idx), ops.gather_rows_i64(self._news_attn_masks, idx)
+
     def _encode_news(self, x, cdd=True):
-        key = "cdd" if cdd else "his"
-        token_id = x[key + "_token_id"].to(self.device)
-        attn_mask = x[key + "_attn_mask"].to(self.device)
+        token_id, attn_mask = self._tokens(x, "cdd" if cdd else "his")
         return self.newsEncoder(token_id, attn_mask)
 
     def _encode_user(self, x=None, his_news_embedding=None, his_mask=None):
@@ -147,10 +164,14 @@ class TwoTowerBaseModel(BaseModel):
         BaseModel.py:198-205).  Titles are encoded independently of each other, so the candidate and
         history titles of the batch go through the news encoder as ONE [B, C+L, T] call (the reference
         makes two calls; per-title results are identical) and are split afterwards."""
-        cdd_ids = x["cdd_token_id"].to(self.device)
-        C = cdd_ids.shape[1]
-        ids = torch.cat([cdd_ids, x["his_token_id"].to(self.device)], dim=1)
-        masks = torch.cat([x["cdd_attn_mask"].to(self.device), x["his_attn_mask"].to(self.device)], dim=1)
+        if "cdd_token_id" in x:
+            cdd_ids = x["cdd_token_id"].to(self.device)
+            C = cdd_ids.shape[1]
+            ids = torch.cat([cdd_ids, x["his_token_id"].to(self.device)], dim=1)
+            masks = torch.cat([x["cdd_attn_mask"].to(self.device), x["his_attn_mask"].to(self.device)], dim=1)
+        else:                               # indices only: one gather for candidates + history
+            C = x["cdd_idx"].shape[1]
+            ids, masks = self._tokens({"all_idx": torch.cat([x["cdd_idx"], x["his_idx"]], dim=1)}, "all")
         _, news = self.newsEncoder(ids, masks)
         cdd_news_embedding = news[:, :C]
         user_embedding = self.userEncoder(news[:, C:], his_mask=x["his_mask"].to(self.device))

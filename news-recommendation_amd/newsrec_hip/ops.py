@@ -83,6 +83,14 @@ def gather_rows(table, ids):
     return out
 
 
+def gather_rows_i64(table, idx):
+    """rows of an int64 [Nn,T] table (news token ids / masks resident in HBM) by news index [...] -> [...,T].
+    The copy kernel moves 32-bit words, so the int64 table is viewed as [Nn, 2T] words: bit-exact."""
+    table, idx = _i64(table, "token table"), _i64(idx, "news index")
+    words = gather_rows(table.view(torch.float32), idx)
+    return words.view(torch.int64)
+
+
 class _Embedding(torch.autograd.Function):
     @staticmethod
     def forward(ctx, table, ids, padding_idx):

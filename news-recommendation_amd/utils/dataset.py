@@ -29,6 +29,10 @@ class MIND(Dataset):
         self.behaviors_cache_dir = os.path.join(root, "behaviors") if "train" in name else \
             os.path.join(root, "behaviors", str(self.impr_size))
         self.enable_fields = list(manager.enable_fields)
+        # with device-side assembly a batch carries news indices only; the [Nn,T] token / mask
+        # tables live in HBM and the rows are gathered there (bit-exact ids, no per-item fancy indexing, no
+        # H->D copy of B x (C+L) x T ids).  --host-assembly (or -d cpu) keeps the reference's batch contract.
+        self.ship_tokens = bool(getattr(manager, "host_assembly", True)) or getattr(manager, "device", "cpu") == "cpu"
         news_num = manager.news_nums[name] + 1               # row 0 = the all-PAD news
         if manager.rank == 0:
             self.logger.info(f"Loading Cache at {name}")
@@ -85,9 +89,10 @@ class MIND(Dataset):
         d = {
             "impr_index": impr_index, "user_index": self.user_indices[impr_index],
             "cdd_idx": cdd_idx, "his_idx": his_idx, "cdd_mask": cdd_mask, "his_mask": his_mask,
-            "cdd_token_id": self.token_ids[cdd_idx], "his_token_id": self.token_ids[his_idx],
-            "cdd_attn_mask": self.attn_masks[cdd_idx], "his_attn_mask": self.attn_masks[his_idx],
         }
+        if self.ship_tokens:
+            d.update({"cdd_token_id": self.token_ids[cdd_idx], "his_token_id": self.token_ids[his_idx],
+                      "cdd_attn_mask": self.attn_masks[cdd_idx], "his_attn_mask": self.attn_masks[his_idx]})
         d.update(extra)
         return d
 

@@ -75,6 +75,9 @@ _FLAGS = [
     (("--debug",), "debug", dict(action="store_true", default=False)),
     # extensions (not in the reference)
     (("--synthetic-plm",), "synthetic_plm", dict(action="store_true", default=False, help="random token table instead of a PLM dir")),
+    (("--host-assembly",), "host_assembly", dict(action="store_true", default=False,
+                                                 help="ship token ids/masks in every batch like the reference (default on a GPU: "
+                                                      "batches carry news indices only and the token rows are gathered on the device)")),
 ]
 
 _PLM = {

@@ -44,7 +44,11 @@ def test_main_twotower_nrms_pair_loss_decreases(tmp_path, monkeypatch):
     loaders = m.prepare()
     model = TwoTowerModel(m, E.TfmNewsEncoder(m), E.TfmUserEncoder(m)).to(m.device).train()
     opt, _ = model.get_optimizer(m, len(loaders["train"]))
+    ds = loaders["train"].dataset
+    assert not ds.ship_tokens                  # default on a GPU: batches carry news indices only
+    model.attach_news_tokens(ds.token_ids, ds.attn_masks)
     x = next(iter(loaders["train"]))
+    assert "cdd_token_id" not in x
     losses = []
     for _ in range(30):                       # overfit one batch: the optimisation loop must drive the loss down
         opt.zero_grad(set_to_none=True)
@@ -63,3 +67,37 @@ def test_main_twotower_nrms_pair_loss_decreases(tmp_path, monkeypatch):
     from main import twotower
     again = twotower.main(m2.device, m2)
     assert again == metrics
+
+
+def test_device_side_batch_assembly_is_bit_exact(tmp_path, monkeypatch):
+    """token rows gathered on the device from the resident [Nn,T] tables equal the rows the
+    reference's __getitem__ ships (--host-assembly), and so does the loss."""
+    import random
+    from utils.manager import Manager
+    from utils.synthetic import write_synthetic_caches
+    from utils.dataset import MIND_Train
+    from models.TwoTower import TwoTowerModel
+    from models.modules import encoder as E
+    from newsrec_hip import ops
+    monkeypatch.chdir(tmp_path)
+    base = f"-bs 8 -ne cnn -ue attn -hd 32 -s demo --synthetic-plm -cr {tmp_path}/cache -dr {tmp_path}/data"
+    m_dev = Manager({"enable_fields": ["title"]}, command=base.split())
+    m_host = Manager({"enable_fields": ["title"]}, command=(base + " --host-assembly").split())
+    for m in (m_dev, m_host):
+        m.news_nums = {"MINDdemo_train": 700, "MINDdemo_dev": 500}
+    write_synthetic_caches(m_dev, n_train_impr=24, n_dev_impr=10, seed=4)
+    d_dev, d_host = MIND_Train(m_dev), MIND_Train(m_host)
+    assert d_host.ship_tokens and not d_dev.ship_tokens
+    collate = torch.utils.data.default_collate
+    random.seed(9)
+    xb_host = collate([d_host[i] for i in range(8)])
+    random.seed(9)
+    xb_dev = collate([d_dev[i] for i in range(8)])
+    assert torch.equal(xb_host["cdd_idx"], xb_dev["cdd_idx"]) and "his_token_id" not in xb_dev
+    tab = torch.from_numpy(d_dev.token_ids).cuda()
+    assert torch.equal(ops.gather_rows_i64(tab, xb_dev["his_idx"].cuda()).cpu(), xb_host["his_token_id"])
+    m_dev.setup(m_dev.device)
+    torch.manual_seed(1)
+    model = TwoTowerModel(m_dev, E.CnnNewsEncoder(m_dev), E.AttnUserEncoder(m_dev)).to(m_dev.device).eval()
+    model.attach_news_tokens(d_dev.token_ids, d_dev.attn_masks)
+    assert float(model(xb_dev)) == float(model(xb_host))
