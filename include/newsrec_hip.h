@@ -179,6 +179,16 @@ int nr_gru_fwd_f32(const float* x, const int64_t* mask, const float* w_ih, const
 size_t nr_gru_bwd_ws_bytes(int64_t B, int64_t L, int64_t Din, int64_t H);
 int nr_gru_bwd_f32(const float* dh_out, const float* x, const float* w_ih, const float* w_hh, int64_t B, int64_t L, int64_t Din, int64_t H, const float* hall, const float* gates, const int32_t* lens, float* dx, float* dw_ih, float* dw_hh, float* db_ih, float* db_hh, void* ws, size_t ws_bytes, void* stream);
 
+/* ---- per-impression ranking metrics — pack_results + compute_metrics, utils/util.py:37-57,126-158,197-250 ----
+ * Result rows (<= Ce-candidate chunks of an impression, models/BaseModel.py:254-260) stay in HBM as flat tensors:
+ * preds [R,Ce] f32, labels [R,Ce] int64 (-1 = padding), masks [R,Ce] uint8.  Impression g = rows
+ * row_start[g] .. +row_count[g]; its candidates are the mask-selected entries in row order.
+ * out [G, 2+nk] f64 = (auc, mrr, ndcg@ks[0], ...); ks_host: HOST array of nk <= 4 cut-offs.
+ * flags [G]: bit 0 = an exact score tie (recompute MRR/nDCG of that impression with numpy's own argsort: its tie
+ * order is not reproducible elsewhere; AUC is exact), 2 = more than 1024 candidates, 4 = a label outside {0,1},
+ * 8 = one class only (the reference raises) — 2/4/8: not computed, fall back to the host functions. */
+int nr_impression_metrics_f64(const float* preds, const int64_t* labels, const uint8_t* masks, int64_t Ce, const int64_t* row_start, const int32_t* row_count, int64_t G, int nk, const int* ks_host, double* out, int32_t* flags, void* stream);
+
 /* ---- helpers of the BERT embedding stage (HF BertEmbeddings behind AllBertNewsEncoder, encoder.py:65,74) ----
  * out[i] = keep(i) ? x[i]/(1-p) : 0 with this library's Philox stream: embeddings.dropout, the one dropout
  * site that is not followed by a LayerNorm.  The same call on the gradient is its backward. */

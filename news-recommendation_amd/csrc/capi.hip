@@ -571,4 +571,15 @@ int nr_gru_bwd_f32(const float* dh_out, const float* x, const float* w_ih, const
     return NR_OK;
 }
 
+// ------------------------------------------------------------------------------------ evaluation metrics
+int nr_impression_metrics_f64(const float* preds, const int64_t* labels, const uint8_t* masks, int64_t Ce, const int64_t* row_start,
+                              const int32_t* row_count, int64_t G, int nk, const int* ks_host, double* out, int32_t* flags,
+                              void* stream) {
+    NR_CHECK_ARG(G >= 0 && Ce > 0 && nk >= 0 && nk <= 4, "impression_metrics: bad sizes (at most 4 nDCG cut-offs)");
+    NR_CHECK_ARG(G == 0 || (preds && labels && masks && row_start && row_count && out && flags), "impression_metrics: null pointer");
+    NR_CHECK_ARG(nk == 0 || ks_host, "impression_metrics: null cut-off list");
+    for (int c = 0; c < nk; ++c) NR_CHECK_ARG(ks_host[c] > 0, "impression_metrics: cut-off %d must be positive", ks_host[c]);
+    return impression_metrics(preds, labels, masks, (int)Ce, row_start, row_count, G, nk, ks_host, out, flags, S(stream));
+}
+
 }  // extern "C"

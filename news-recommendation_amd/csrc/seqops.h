@@ -38,4 +38,9 @@ int gru_gate_fwd(const float* gi, const float* gh, const float* hprev, const int
 int gru_gate_bwd(const float* dh, const float* saved, const float* hprev, const int* lens, float* dgi, float* dgh, float* dh_direct,
                  int B, int L, int H, int t, hipStream_t s);
 
+
+// per-impression AUC / MRR / nDCG@k on the device (metrics.hip)
+int impression_metrics(const float* preds, const int64_t* labels, const uint8_t* masks, int Ce, const int64_t* row_start,
+                       const int32_t* row_count, int64_t G, int nk, const int* ks, double* out, int32_t* flags, hipStream_t s);
+
 }  // namespace nr

@@ -24,7 +24,7 @@ import torch.distributed as dist
 from tqdm import tqdm
 
 from newsrec_hip import ops
-from utils.util import pack_results, compute_metrics, HipAdam, linear_warmup_lambda
+from utils.util import pack_results, compute_metrics, device_compute_metrics, HipAdam, linear_warmup_lambda
 
 
 class BaseModel(nn.Module):
@@ -229,7 +229,7 @@ class TwoTowerBaseModel(BaseModel):
         else:
             self.news_embeddings = local
 
-    def _predict(self, manager, loader, with_labels):
+    def _predict(self, manager, loader, with_labels, to_host=True):
         """score this rank's shard; results stay on the device as flat typed tensors until the end."""
         impr, masks, labels, preds = [], [], [], []
         for x in tqdm(loader, ncols=80, desc="Predicting", disable=self.rank != 0):
@@ -250,7 +250,8 @@ class TwoTowerBaseModel(BaseModel):
             if self.rank != 0:
                 return None
             out = [torch.cat(g) for g in gathered]
-        return [t.cpu().numpy() for t in out]
+            out[1] = out[1].bool()
+        return [t.cpu().numpy() for t in out] if to_host else out
 
     def _dev(self, manager, loaders):
         self.encode_news(manager, loaders["news"])
@@ -260,6 +261,31 @@ class TwoTowerBaseModel(BaseModel):
         impr, masks, preds, labels = res
         labels, preds = pack_results(impr, masks.astype(np.bool_), labels.astype(np.int32), preds.astype(np.float32))
         return labels, preds
+
+    @torch.no_grad()
+    def dev(self, manager, loaders, log=False):
+        """same contract as BaseModel.dev; on a GPU the per-impression metrics are computed from the result
+        tensors where they are (device_compute_metrics), the host regrouping + python loops only as fallback"""
+        if self.device == "cpu" or getattr(manager, "host_metrics", False):
+            return super().dev(manager, loaders, log)
+        self.eval()
+        self.encode_news(manager, loaders["news"])
+        res = self._predict(manager, loaders["dev"], with_labels=True, to_host=False)
+        metrics = None
+        if self.rank == 0:
+            impr, masks, preds, labels = res
+            metrics = device_compute_metrics(impr, masks, preds, labels, manager.metrics)
+            if metrics is None:
+                l_, p_ = pack_results(impr.cpu().numpy(), masks.cpu().numpy().astype(np.bool_), labels.cpu().numpy().astype(np.int32),
+                                      preds.cpu().numpy().astype(np.float32))
+                metrics = compute_metrics(l_, p_, manager.metrics)
+            metrics["main"] = metrics["auc"]
+            self.logger.info(metrics)
+            if log:
+                manager._log(self.name, metrics)
+        if manager.distributed:
+            _barrier(self.device)
+        return metrics
 
     def _test(self, manager, loaders):
         self.encode_news(manager, loaders["news"])

@@ -634,6 +634,23 @@ def score_from_table(table, cdd_idx, user):
     return logits
 
 
+# ----------------------------------------------------------------------------- evaluation metrics
+def impression_metrics(preds, labels, masks, row_start, row_count, ks):
+    """per-impression (auc, mrr, ndcg@k...) [G, 2+len(ks)] float64 and flags [G] int32 (see newsrec_hip.h);
+    preds [R,Ce] f32, labels [R,Ce] int64, masks [R,Ce] bool/uint8, row_start [G] int64, row_count [G] int32."""
+    preds, labels = _f32(preds, "preds"), _i64(labels, "labels")
+    masks = masks.to(torch.uint8).contiguous()
+    row_start = _i64(row_start, "row_start")
+    row_count = row_count.to(torch.int32).contiguous()
+    G, Ce = row_start.numel(), preds.shape[1]
+    out = torch.empty(G, 2 + len(ks), dtype=torch.float64, device=preds.device)
+    flags = torch.empty(G, dtype=torch.int32, device=preds.device)
+    karr = (C.c_int * max(len(ks), 1))(*[int(k) for k in ks])
+    check(lib().nr_impression_metrics_f64(_p(preds), _p(labels), _p(masks), Ce, _p(row_start), _p(row_count), G, len(ks), karr,
+                                          _p(out), _p(flags), _stream()), "nr_impression_metrics_f64")
+    return out, flags
+
+
 # ----------------------------------------------------------------------------- Adam
 def adam_step(param, grad, exp_avg, exp_avg_sq, step, lr, beta1=0.9, beta2=0.999, eps=1e-8):
     check(lib().nr_adam_step_f32(_p(param), _p(grad), _p(exp_avg), _p(exp_avg_sq), param.numel(), lr, beta1, beta2, eps, step,

@@ -125,6 +125,74 @@ def compute_metrics(labels, preds, metrics):
     return res
 
 
+def parse_metrics(metrics):
+    """-> (want_auc, want_mrr, ndcg cut-offs) or None when a metric the device kernel does not produce is asked for"""
+    want_auc = want_mrr = False
+    ks = []
+    for metric in metrics:
+        if metric == "auc":
+            want_auc = True
+        elif metric == "mean_mrr":
+            want_mrr = True
+        elif metric.startswith("ndcg"):
+            parts = metric.split("@")
+            ks += [int(t) for t in parts[1].split(";")] if len(parts) > 1 else [1, 2]
+        else:
+            return None
+    ks = list(dict.fromkeys(ks))
+    return (want_auc, want_mrr, ks) if len(ks) <= 4 else None
+
+
+def device_compute_metrics(impr, masks, preds, labels, metrics):
+    """compute_metrics(pack_results(...)) without leaving the GPU: `impr` [R] int64, `masks`
+    [R,Ce] bool, `preds` [R,Ce] f32, `labels` [R,Ce] int64 are the device tensors the scoring pass produced.
+    Returns the same dict as compute_metrics, or None when the host path has to run (metrics the kernel does
+    not know, impressions whose rows are not adjacent, > 1024 candidates, non-binary labels).
+    Impressions with an exact score tie get their MRR / nDCG recomputed on the host with the reference's numpy
+    expression (np.argsort(...)[::-1]: its tie order is numpy's own), so the result equals the host path's."""
+    from newsrec_hip import ops
+    spec = parse_metrics(metrics)
+    if spec is None or impr.numel() == 0:
+        return None
+    want_auc, want_mrr, ks = spec
+    new = torch.ones_like(impr, dtype=torch.bool)
+    new[1:] = impr[1:] != impr[:-1]
+    starts = torch.nonzero(new).flatten()
+    if torch.unique(impr).numel() != starts.numel():
+        return None                                   # an impression's rows are not adjacent: pack_results' regrouping needed
+    counts = torch.diff(torch.cat([starts, torch.tensor([impr.numel()], device=impr.device)])).to(torch.int32)
+    out, flags = ops.impression_metrics(preds, labels, masks, starts, counts, ks)
+    flags = flags.cpu().numpy()
+    if (flags & 14).any():
+        return None
+    out = out.cpu().numpy()
+    tied = np.flatnonzero(flags & 1)
+    if tied.size and (want_mrr or ks):
+        st, ct = starts.cpu().numpy(), counts.cpu().numpy()
+        rows = np.concatenate([np.arange(st[g], st[g] + ct[g]) for g in tied])
+        ridx = torch.from_numpy(rows).to(impr.device)
+        m_h, p_h, l_h = masks[ridx].cpu().numpy().astype(np.bool_), preds[ridx].cpu().numpy(), labels[ridx].cpu().numpy()
+        pos = 0
+        for g in tied:
+            sl = slice(pos, pos + ct[g])
+            pos += ct[g]
+            y, sc = l_h[sl][m_h[sl]].astype(np.int32), p_h[sl][m_h[sl]].astype(np.float32)
+            out[g, 1] = mrr_score(y, sc)
+            for c, k in enumerate(ks):
+                out[g, 2 + c] = ndcg_score(y, sc, k)
+    res = {}
+    for metric in metrics:
+        if metric == "auc":
+            res["auc"] = round(np.mean(out[:, 0]), 4)
+        elif metric == "mean_mrr":
+            res["mean_mrr"] = round(np.mean(out[:, 1]), 4)
+        else:
+            parts = metric.split("@")
+            for k in ([int(t) for t in parts[1].split(";")] if len(parts) > 1 else [1, 2]):
+                res["ndcg@{}".format(k)] = round(np.mean(out[:, 2 + ks.index(k)]), 4)
+    return res
+
+
 class Sequential_Sampler:
     """rank r reads the contiguous slice [round(n/ws*r), round(n/ws*(r+1)))"""
 

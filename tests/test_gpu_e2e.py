@@ -59,6 +59,9 @@ def test_main_twotower_nrms_pair_loss_decreases(tmp_path, monkeypatch):
     assert losses[-1] < 0.5 * losses[0], losses[::5]
     metrics = model.dev(m, loaders)
     assert metrics["main"] == metrics["auc"]
+    m.host_metrics = True                      # the reference's host regrouping + python metric loops
+    assert model.dev(m, loaders) == metrics    # ... give exactly what the device kernel gave
+    m.host_metrics = False
     # dev mode through the entry point, loading the checkpoint just written
     m.save(model, 1, best=True)
     m2 = Manager({"enable_fields": ["title"]}, command=f"-m dev -ne tfm -ue tfm -hd 48 -hn 4 -s demo --synthetic-plm "

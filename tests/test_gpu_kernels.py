@@ -419,3 +419,58 @@ def test_gru_final_state(ops, B, L, D):
     with torch.no_grad():
         assert torch.equal(ops.gru_final_state(x.cuda(), mask.cuda(), W["weight_ih_l0"], W["weight_hh_l0"], W["bias_ih_l0"],
                                                W["bias_hh_l0"]), out.detach())
+
+
+# ------------------------------------------------------------------ on-device per-impression metrics
+def test_device_metrics_match_reference_golden():
+    """the reference's own pack_results + compute_metrics output (tests/golden/metrics.npz: ragged impressions,
+    exact ties, padded chunks) reproduced from flat device tensors"""
+    from helpers import GOLDEN
+    import os
+    from utils.util import device_compute_metrics, compute_metrics, pack_results
+    z = np.load(os.path.join(GOLDEN, "metrics.npz"), allow_pickle=False)
+    impr = torch.from_numpy(z["impr_indices"]).long().cuda()
+    masks = torch.from_numpy(z["masks"]).cuda()
+    preds = torch.from_numpy(z["preds"]).cuda()
+    labels = torch.from_numpy(z["labels"]).long().cuda()
+    names = ["auc", "mean_mrr", "ndcg@5", "ndcg@10"]
+    got = device_compute_metrics(impr, masks, preds, labels, names)
+    assert got is not None
+    ref = z["result"]
+    assert [got["auc"], got["mean_mrr"], got["ndcg@5"], got["ndcg@10"]] == [round(float(v), 4) for v in ref]
+    host = compute_metrics(*pack_results(z["impr_indices"], z["masks"], z["labels"], z["preds"]), names)
+    assert got == host
+
+
+@pytest.mark.parametrize("n_impr,Ce,max_cand,ties", [(3000, 20, 120, False), (500, 20, 300, True), (64, 6, 40, True), (1, 20, 2, False)])
+def test_device_metrics_vs_host(n_impr, Ce, max_cand, ties):
+    from utils.util import device_compute_metrics, compute_metrics, pack_results
+    rng = np.random.RandomState(17)
+    impr, masks, labels, preds = [], [], [], []
+    for imp in range(n_impr):
+        n = rng.randint(2, max_cand + 1)
+        lab = (rng.rand(n) < 0.2).astype(np.int64)
+        lab[rng.randint(n)] = 1
+        lab[(np.argmax(lab) + 1) % n] = 0
+        sc = rng.randn(n).astype(np.float32)
+        if ties and imp % 3 == 0:
+            sc = np.round(sc, 1)
+        for s in range(0, n, Ce):
+            m = min(Ce, n - s)
+            impr.append(imp * 7 + 3)
+            masks.append(np.arange(Ce) < m)
+            labels.append(np.concatenate([lab[s:s + m], -np.ones(Ce - m, dtype=np.int64)]))
+            preds.append(np.concatenate([sc[s:s + m], rng.randn(Ce - m).astype(np.float32)]))
+    impr, masks, labels, preds = np.asarray(impr), np.asarray(masks), np.asarray(labels), np.asarray(preds, dtype=np.float32)
+    names = ["auc", "mean_mrr", "ndcg@5;10", "ndcg@1"]
+    host = compute_metrics(*pack_results(impr, masks, labels.astype(np.int32), preds), names)
+    got = device_compute_metrics(torch.from_numpy(impr).cuda(), torch.from_numpy(masks).cuda(), torch.from_numpy(preds).cuda(),
+                                 torch.from_numpy(labels).cuda(), names)
+    assert got == host
+    # rows of one impression that are NOT adjacent need the host regrouping: the device path must decline
+    if n_impr > 1:
+        perm = np.arange(len(impr))
+        perm[[0, -1]] = perm[[-1, 0]]
+        if impr[0] != impr[-1] and (impr == impr[0]).sum() > 1:
+            assert device_compute_metrics(torch.from_numpy(impr[perm]).cuda(), torch.from_numpy(masks[perm]).cuda(),
+                                          torch.from_numpy(preds[perm]).cuda(), torch.from_numpy(labels[perm]).cuda(), names) is None
