@@ -186,6 +186,24 @@ class TwoTowerBaseModel(BaseModel):
         the scoring kernel gathers rows of the cache by index (segmented gather-dot)."""
         cdd_idx = x["cdd_idx"].to(self.device, non_blocking=True)
         his_idx = x["his_idx"].to(self.device, non_blocking=True)
+        his_mask = x.get("his_mask")
+        # the <=Ce-candidate chunks of one impression share the user's history: encode each user once per run of
+        # equal impr_index (the reference re-encodes it for every chunk; same vectors, ~2.5x fewer on MIND)
+        inv = None
+        if "impr_index" in x and his_idx.shape[0] > 1:
+            impr = x["impr_index"].to(self.device)
+            first = torch.ones_like(impr, dtype=torch.bool)
+            first[1:] = impr[1:] != impr[:-1]
+            if not bool(first.all()):
+                inv = torch.cumsum(first, 0) - 1
+                his_idx = his_idx[first]
+                his_mask = his_mask.to(self.device)[first] if his_mask is not None else None
+        user = self._user_from_cache(his_idx, his_mask)
+        if inv is not None:
+            user = ops.gather_rows(user.reshape(user.shape[0], -1), inv)
+        return ops.score_from_table(self.news_embeddings, cdd_idx, user)
+
+    def _user_from_cache(self, his_idx, his_mask):
         kind = type(self.userEncoder).__name__
         if kind == "SumUserEncoder":
             user = ops.seq_reduce_from_table(self.news_embeddings, his_idx, mean=False)
@@ -195,8 +213,8 @@ class TwoTowerBaseModel(BaseModel):
             user = ops.pool_from_table(self.news_embeddings, his_idx, self.userEncoder.user_query)
         else:
             his = ops.gather_rows(self.news_embeddings, his_idx)
-            user = self._encode_user(his_news_embedding=his, his_mask=x["his_mask"].to(self.device))
-        return ops.score_from_table(self.news_embeddings, cdd_idx, user)
+            user = self._encode_user(his_news_embedding=his, his_mask=his_mask.to(self.device))
+        return user
 
     @torch.no_grad()
     def encode_news(self, manager, loader_news):
