@@ -523,6 +523,10 @@ static int launch_tiled(const GemmParams& p, hipStream_t s) {
 // and many n-tiles to share the tall A tile through L2: measured on the NRMS shapes it wins for dW[300,1200]
 // (85 vs 79 TF/s) and loses for dW[900,300] / dW[300,300] (74 vs 78, 51 vs 59)
 static bool tall_tile(int M, int N, int K) { return K >= 8192 && N >= 1024 && cdiv(M, 320) * 320 < cdiv(M, 128) * 128; }
+// ... and 64-row tiles when they pad M less than 128-row ones (M = 300: 320 vs 384 rows; dW[300,300] 52 -> 66 TF/s,
+// dW[900,300] 78 -> 83, dW[1200,300] 84 -> 90)
+static bool short_tile(int M) { return cdiv(M, 64) * 64 < cdiv(M, 128) * 128; }
+static int dw_tile_rows(int M, int N, int K) { return tall_tile(M, N, K) ? 320 : (short_tile(M) ? 64 : 128); }
 
 size_t gemm_workspace_bytes(int M, int N, int ksplit) {
     return ksplit > 1 ? (size_t)ksplit * M * N * sizeof(float) : 0;
@@ -532,7 +536,7 @@ int choose_ksplit(int M, int N, int K) {
     // dW GEMMs: tiny MxN, huge K.  Two pulls (swept on MI355X, tools/dw_lab.sh): enough workgroups to fill the
     // chip (>= 512), and slices of ~32 k-tiles — shorter slices than the fill needs only add slab traffic, longer
     // ones leave the single-buffered loop latency-bound (dW[1200,300]: 68 TF/s at 512 workgroups, 85 at 2048+)
-    const int tiles = cdiv(M, tall_tile(M, N, K) ? 320 : 128) * cdiv(N, 64);
+    const int tiles = cdiv(M, dw_tile_rows(M, N, K)) * cdiv(N, 64);
     const int kt = cdiv(K, BK);
     if (tiles >= 2048 || kt < 8) return 1;   // (288 tiles on 256 CUs would run as two unbalanced rounds: keep splitting)
     int ks = std::max((512 + tiles - 1) / tiles, kt / 32);
@@ -592,6 +596,7 @@ int gemm_f32(GemmParams p, bool a_kc, bool b_kc, float* workspace, size_t ws_byt
     else if (a_kc && !b_kc)  rc = small ? launch_tiled<true, false, 1, 1>(q, s) : wide ? launch_tiled<true, false, 2, 2>(q, s) : launch_tiled<true, false, 2, 1>(q, s);
     else if (!a_kc && !b_kc) {
         if (!p.conv_on && !wide && (p.epi == EPI_NONE || p.ksplit > 1) && tall_tile(p.M, p.N, p.K)) rc = launch_tiled<false, false, 5, 1>(q, s);
+        else if (!wide && short_tile(p.M)) rc = launch_tiled<false, false, 1, 1>(q, s);
         else rc = wide ? launch_tiled<false, false, 2, 2>(q, s) : launch_tiled<false, false, 2, 1>(q, s);
     }
     else { set_error("gemm: layout (A red-major, B k-contig) not built"); return NR_ERR_UNSUPPORTED; }
