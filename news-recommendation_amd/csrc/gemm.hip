@@ -591,7 +591,9 @@ int gemm_f32(GemmParams p, bool a_kc, bool b_kc, float* workspace, size_t ws_byt
     const bool wide = (cdiv(p.N, 128) * 128 == cdiv(p.N, 64) * 64) && p.N >= 128;
     int rc;
     // few 128-row tiles (the user tower: 1600 history rows) leave most CUs idle: halve the tile
-    const bool small = (int64_t)cdiv(p.M, 128) * cdiv(p.N, 64) * p.ksplit < 192;
+    // ... and so does a short, narrow product (N <= 320, K <= 512: out-proj / pooling projection at 300-d, +5-9 %):
+    // ten k-tiles per workgroup are mostly prologue/epilogue, which 7 resident waves per SIMD overlap better
+    const bool small = (int64_t)cdiv(p.M, 128) * cdiv(p.N, 64) * p.ksplit < 192 || (p.N <= 320 && p.K <= 512);
     if (a_kc && b_kc)        rc = small ? launch_tiled<true, true, 1, 1>(q, s) : wide ? launch_tiled<true, true, 2, 2>(q, s) : launch_tiled<true, true, 2, 1>(q, s);
     else if (a_kc && !b_kc)  rc = small ? launch_tiled<true, false, 1, 1>(q, s) : wide ? launch_tiled<true, false, 2, 2>(q, s) : launch_tiled<true, false, 2, 1>(q, s);
     else if (!a_kc && !b_kc) {
