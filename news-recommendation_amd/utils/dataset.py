@@ -5,8 +5,9 @@ contract).  Cache layout and per-item dict keys are the reference's (utils/datas
     {cache_root}/MIND/MIND{scale}_train/behaviors/behaviors.pkl          imprs, user_indices, histories, negatives
     {cache_root}/MIND/MIND{scale}_{dev,test}/behaviors/{impr_size}/behaviors.pkl   imprs, (labels), histories, user_indices
 
-Raw-TSV tokenisation / behaviour caching (reference :298-427) is a later row; a
-missing cache is an error here, and utils/synthetic.py writes MIND-shaped caches for tests/bench.
+A missing cache is built on rank 0 from {data_root}/MIND/MIND{scale}_{split}/{news,behaviors}.tsv by
+utils/cache.py (reference :47-53, :298-427); utils/synthetic.py writes MIND-shaped caches
+for tests/bench.
 """
 import logging
 import os
@@ -34,6 +35,11 @@ class MIND(Dataset):
         # H->D copy of B x (C+L) x T ids).  --host-assembly (or -d cpu) keeps the reference's batch contract.
         self.ship_tokens = bool(getattr(manager, "host_assembly", True)) or getattr(manager, "device", "cpu") == "cpu"
         news_num = manager.news_nums[name] + 1               # row 0 = the all-PAD news
+        if manager.rank == 0:
+            from utils.cache import ensure_caches
+            ensure_caches(manager, data_dir, self.news_cache_root, self.behaviors_cache_dir)
+        if getattr(manager, "distributed", False):
+            manager.barrier()
         if manager.rank == 0:
             self.logger.info(f"Loading Cache at {name}")
         if load_news:

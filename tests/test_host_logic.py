@@ -177,3 +177,105 @@ def test_checkpoint_roundtrip(tmp_path, monkeypatch):
         assert torch.equal(a, b), k
     m._log(model.name, {"auc": 0.5})
     assert "TwoTower-Tfm-Tfm" in open("performance.log").read()
+
+
+def _write_cache_fixture(tmp_path):
+    """lay the fixture's TSV files and vocabulary out like {data_root}/MIND/MINDlarge_{split}/ + PLM/bert"""
+    import json
+    fx = json.load(open(os.path.join(ROOT, "tests", "golden", "cache_pipeline.json"), encoding="utf-8"))
+    data_root, cache_root = str(tmp_path / "Data"), str(tmp_path / "cache")
+    plm_dir = os.path.join(data_root, "PLM", "bert")
+    os.makedirs(plm_dir)
+    with open(os.path.join(plm_dir, "vocab.txt"), "w", encoding="utf-8") as f:
+        f.write("\n".join(fx["vocab"]) + "\n")
+    for split, blob in fx["splits"].items():
+        d = os.path.join(data_root, "MIND", "MINDlarge_" + split)
+        os.makedirs(d)
+        for name in ("news", "behaviors"):
+            with open(os.path.join(d, name + ".tsv"), "w", encoding="utf-8") as f:
+                f.write("\n".join(blob[name + "_tsv"]) + "\n")
+    mgr = types.SimpleNamespace(plm_dir=plm_dir, max_title_length=fx["max_title_length"], max_abs_length=fx["max_abs_length"],
+                                impr_size=fx["impr_size"], data_root=data_root, cache_root=cache_root, scale="large")
+    return fx, mgr
+
+
+def test_tsv_cache_pipeline_matches_reference(tmp_path):
+    """tokenised news, nid2index, uid2index and the three behaviour caches equal what the
+    reference's cache_news / cache_behaviors wrote for the same TSV files (tests/golden/make_golden_cache.py)."""
+    from utils import cache as C
+    from utils.util import load_pickle
+    fx, mgr = _write_cache_fixture(tmp_path)
+    for split, blob in fx["splits"].items():
+        d = os.path.join(mgr.data_root, "MIND", "MINDlarge_" + split)
+        news_cache = os.path.join(mgr.cache_root, "MIND", "MINDlarge_" + split, "news")
+        beh_cache = os.path.join(mgr.cache_root, "MIND", "MINDlarge_" + split, "behaviors")
+        if split != "train":
+            beh_cache = os.path.join(beh_cache, str(mgr.impr_size))
+        assert C.ensure_caches(mgr, d, news_cache, beh_cache)
+        assert load_pickle(os.path.join(news_cache, "title_token_ids.pkl")) == blob["title_token_ids"]
+        assert load_pickle(os.path.join(news_cache, "abs_token_ids.pkl")) == blob["abs_token_ids"]
+        assert load_pickle(os.path.join(news_cache, "nid2index.pkl")) == blob["nid2index"]
+        beh = load_pickle(os.path.join(beh_cache, "behaviors.pkl"))
+        assert list(beh.keys()) == list(blob["behaviors"].keys())
+        for k, v in blob["behaviors"].items():
+            got = [list(x) if isinstance(x, tuple) else x for x in beh[k]]
+            assert got == v, (split, k)
+        assert all(isinstance(x, tuple) for x in beh["imprs"])
+    uid = load_pickle(os.path.join(mgr.cache_root, "MIND", "uid2index.pkl"))
+    assert uid == fx["uid2index"] and list(uid) == list(fx["uid2index"])
+
+
+def test_wordpiece_edge_cases(tmp_path):
+    from utils.cache import WordPieceTokenizer
+    fx, mgr = _write_cache_fixture(tmp_path)
+    tok = WordPieceTokenizer.from_pretrained(mgr.plm_dir)
+    v = tok.vocab
+    assert tok.encode("", max_length=12) == [v["[CLS]"], v["[SEP]"]]
+    assert tok.encode("The  GAME ", max_length=12) == [v["[CLS]"], v["the"], v["game"], v["[SEP]"]]
+    assert tok.encode("x" * 101) == [v["[CLS]"], v["[UNK]"], v["[SEP]"]]
+    assert tok.encode("games") == [v["[CLS]"], v["game"], v["##s"], v["[SEP]"]]
+    assert tok.encode("the the the the", max_length=4) == [v["[CLS]"], v["the"], v["the"], v["[SEP]"]]
+    assert tok.encode("win\x00!​") == [v["[CLS]"], v["win"], v["!"], v["[SEP]"]]
+    with pytest.raises(FileNotFoundError):
+        WordPieceTokenizer.from_pretrained(str(tmp_path / "nowhere"))
+
+
+def test_dataset_builds_caches_from_tsv(tmp_path):
+    """MIND_Train over raw TSV files only: the caches appear on first use and the items come out shaped"""
+    from utils import dataset as D
+    fx, mgr = _write_cache_fixture(tmp_path)
+    full = helpers.make_manager(device="cpu", scale="large", data_root=mgr.data_root, cache_root=mgr.cache_root, plm_dir=mgr.plm_dir,
+                                max_title_length=mgr.max_title_length, max_abs_length=mgr.max_abs_length, impr_size=mgr.impr_size,
+                                title_length=8, abs_length=8, mode="train", host_assembly=True,
+                                news_nums={"MINDlarge_train": 40, "MINDlarge_dev": 30, "MINDlarge_test": 30},
+                                special_token_ids={"[PAD]": 0, "[SEP]": fx["vocab"].index("[SEP]"), "[CLS]": fx["vocab"].index("[CLS]")})
+    random.seed(0)
+    ds = D.MIND_Train(full)
+    assert len(ds) == len(fx["splits"]["train"]["behaviors"]["imprs"])
+    item = ds[0]
+    assert item["cdd_token_id"].shape == (1 + full.negative_num, 8) and item["his_token_id"].shape == (full.his_size, 8)
+    first = fx["splits"]["train"]["title_token_ids"][0][:8]
+    row = ds.token_ids[1]
+    assert row[0] == first[0] and (row[:len(first) - 1] == np.asarray(first[:-1])).all()
+    dev = D.MIND_Dev(full)
+    assert len(dev) == len(fx["splits"]["dev"]["behaviors"]["imprs"])
+    assert os.path.exists(os.path.join(mgr.cache_root, "MIND", "MINDlarge_dev", "behaviors", str(mgr.impr_size), "behaviors.pkl"))
+
+
+def test_wordpiece_equals_hf_tokenizer_on_fuzzed_text(tmp_path):
+    """the call the reference makes is transformers' BERT tokenizer (dataset.py:306,323): where that library is
+    importable, random strings over accents, CJK, separators, control characters, emoji and special tokens must
+    encode identically.  (A third-party library, not the reference; the reference-made fixture is the pin.)"""
+    tf = pytest.importorskip("transformers")
+    from utils.cache import WordPieceTokenizer
+    fx, mgr = _write_cache_fixture(tmp_path)
+    tok = WordPieceTokenizer.from_pretrained(mgr.plm_dir)
+    hf = tf.BertTokenizerFast(os.path.join(mgr.plm_dir, "vocab.txt"))
+    rng = random.Random(7)
+    pool = list("abcxyzABC019 .,!?'-_#$ \t") + [chr(c) for c in (
+        0xe9, 0xef, 0xf1, 0x4e2d, 0x56fd, 0x6587, 0x2014, 0x2019, 0x201c, 0xa3, 0x20ac, 0xa0, 0x3000, 0x200b, 0x1c, 0x85, 0x2028,
+        0x2029, 0, 0xfffd, 0x301, 0xdf, 0x130, 0x1c4, 0xfb01, 0xff71, 0x61f, 0xe01, 0xd55c, 0x1f600, 0xb, 0xc, 0xad, 0x200d, 0xfeff,
+        0x1680, 0x2003)] + ["[SEP]", "[UNK]", "[MASK]", " the ", " game", " trump"]
+    for _ in range(3000):
+        s = "".join(rng.choice(pool) for _ in range(rng.randint(0, 30)))
+        assert tok.encode(s, 16) == hf.encode(s, max_length=16, truncation=True), repr(s)
