@@ -30,6 +30,7 @@ V, E, D, H, T, L, K = 30522, 300, 300, 12, 32, 50, 4
 NEWS_TRAIN = 101527 + 1        # MINDlarge_train rows (+1 pad row), reference manager.py:175
 NEWS_DEV = 72023 + 1           # MINDlarge_dev
 PEAK_F32_MATRIX_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 peak
+PEAK_BF16_MATRIX_TFLOPS = 2500.0  # dense bf16 MFMA peak (no sparsity)
 PEAK_HBM_GBS = 8000.0
 
 
@@ -199,6 +200,9 @@ def main():
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="nrms",
                     help="nrms = the headline workload (BASELINE configs[1]); the others are extra measurements "
                          "(no roofline/cpu_baseline/eval legs)")
+    ap.add_argument("--gemm", choices=["fp32", "bf16"], default="fp32",
+                    help="matrix-core operand precision (nr_set_gemm_compute): bf16 is the 1e-2-parity build of SURVEY §8 a7, "
+                         "an extra measurement next to the fp32 headline")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-eval", action="store_true")
     args = ap.parse_args()
@@ -213,6 +217,7 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
     from newsrec_hip import ops
+    ops.set_gemm_compute(args.gemm)
 
     B = args.batch_size
     extra = args.workload != "nrms"
@@ -273,9 +278,12 @@ def main():
     ops.prof_enable(False)
     gm = fam["gemm"]
     gemm_tflops = gm["work_per_step"] / (gm["ms_per_step"] * 1e-3) / 1e12 if gm["ms_per_step"] > 0 else 0.0
-    roofline = {"kernel": "gemm_f32_kernel (v_mfma_f32_32x32x2_f32), all GEMM launches of one train step",
-                "bound": "mfma", "achieved": round(gemm_tflops, 2), "peak": PEAK_F32_MATRIX_TFLOPS, "unit": "TFLOP/s",
-                "frac": round(gemm_tflops / PEAK_F32_MATRIX_TFLOPS, 4), **pmc_traffic(),
+    bf16 = args.gemm == "bf16"          # mixed launches then: large products on the bf16 pipe (dense peak 2500 TFLOP/s), the rest fp32
+    peak = PEAK_BF16_MATRIX_TFLOPS if bf16 else PEAK_F32_MATRIX_TFLOPS
+    roofline = {"kernel": ("gemm_bf16_kernel (v_mfma_f32_32x32x16_bf16) + gemm_f32_kernel for small/conv products" if bf16 else
+                           "gemm_f32_kernel (v_mfma_f32_32x32x2_f32)") + ", all GEMM launches of one train step",
+                "bound": "mfma", "achieved": round(gemm_tflops, 2), "peak": peak, "unit": "TFLOP/s",
+                "frac": round(gemm_tflops / peak, 4), **({"traffic": None} if bf16 else pmc_traffic()),
                 "launches_per_step": gm["launches_per_step"], "avg_launch_ms": round(gm["ms_per_step"] / max(gm["launches_per_step"], 1), 5),
                 "flops_per_step": gm["work_per_step"]}
     hbm_step = {}
@@ -291,7 +299,7 @@ def main():
         "metric": "train impressions/sec (node), NRMS-shape MIND-large; eval impressions/sec",
         "value": round(value, 2), "unit": "impressions/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f32", "data": "synthetic",
+        "dtype": "f32" if args.gemm == "fp32" else "bf16 operands, f32 accumulate (tensors f32)", "data": "synthetic",
         "config": {"workload": WORKLOADS[args.workload][4] + ", train step = fwd+bwd+Adam with dropout 0.1",
                    "per_gpu_batch": B, "global_batch": B * world, "vocab": V, "parallelism": f"dp{world}"},
         "loss": round(final_loss, 5),

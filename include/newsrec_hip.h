@@ -47,6 +47,15 @@ enum { NR_FAM_GEMM = 0, NR_FAM_GATHER = 1, NR_FAM_ATTN = 2, NR_FAM_LN = 3, NR_FA
 int nr_prof_enable(int on);
 int nr_prof_read(int family, double* ms, int64_t* launches, double* work);
 
+/* ---- matrix-core precision of the GEMM family -------------------------------------------
+ * mode 0 (default): exact fp32 MFMA (the 1e-5 parity bar).  mode 1: operands rounded to bf16 on their way into
+ * LDS, f32 accumulate (v_mfma_f32_32x32x16_bf16) for every non-conv product with M, N, K >= 128; tensors in HBM
+ * stay fp32.  This is the "bf16-MFMA build" of SURVEY §8 a7 (AllBertNewsEncoder, encoder.py:62-77; parity bar
+ * 1e-2); the closest thing in the reference is running the model under torch.autocast.  Process-wide and sticky:
+ * set it before the first step.  nr_set_gemm_compute returns NR_ERR_ARG for an unknown mode. */
+int nr_set_gemm_compute(int mode);
+int nr_get_gemm_compute(void);
+
 /* ---- (i) token-embedding gather — nn.Embedding lookup, models/modules/encoder.py:52,135 ------
  * out[r,:] = table[ids[r],:] (bit-exact).  *oob_flag (device int, may be NULL) is set to 1 if any
  * id is outside [0,V) (such rows read row 0 instead of faulting).

@@ -142,6 +142,12 @@ using namespace nr;
 extern "C" {
 
 int nr_version(void) { return 1; }
+int nr_set_gemm_compute(int mode) {
+    NR_CHECK_ARG(mode == 0 || mode == 1, "nr_set_gemm_compute: mode must be 0 (fp32) or 1 (bf16 operands)");
+    nr::set_gemm_compute(mode);
+    return NR_OK;
+}
+int nr_get_gemm_compute(void) { return nr::get_gemm_compute(); }
 const char* nr_last_error(void) { return g_err; }
 
 int nr_prof_enable(int on) {

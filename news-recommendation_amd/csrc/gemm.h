@@ -42,5 +42,8 @@ int gemm_f32(GemmParams p, bool a_kc, bool b_kc, float* workspace, size_t ws_byt
 size_t gemm_workspace_bytes(int M, int N, int ksplit);
 int choose_ksplit(int M, int N, int K);
 bool gemm_fast_path(const GemmParams& p, bool a_kc, bool b_kc);
+// 0: exact fp32 matrix cores (default); 1: operands rounded to bf16 in LDS, f32 accumulate (large non-conv products only)
+void set_gemm_compute(int mode);
+int get_gemm_compute();
 
 }  // namespace nr

@@ -29,6 +29,7 @@
 // x[(r-1)*E] (r = m*T+t), with the first/last E zeroed at t==0 / t==T-1.
 #include "common.h"
 #include "gemm.h"
+#include <atomic>
 
 namespace nr {
 
@@ -252,6 +253,100 @@ __device__ __forceinline__ void store_block(const f32x16 (&acc)[WM][NJ], float* 
     }
 }
 
+// the same block store with the epilogue chosen at run time (wave-uniform branches instead of one instantiation per
+// epilogue): the bf16 kernel's k-loop is short on registers, and 16 inlined epilogue variants pushed it into scratch
+template <int WM, int NJ, bool CHECK>
+__device__ __forceinline__ void store_block_rt(const f32x16 (&acc)[WM][NJ], float* C, int mw, int nw, int l31, int h,
+                                            bool use_bias, int epi, const GemmParams& p) {
+    const int64_t ldc = p.ldc, ldaux = p.ldaux, ldaux2 = p.ldaux2, ldout2 = p.ldout2;
+    const bool has_aux = epi == EPI_ADD_AUX || epi == EPI_MUL_GELU_GRAD || epi == EPI_ADD_AUX_RELUMASK;
+    const bool has_aux2 = epi == EPI_ADD_AUX_RELUMASK || epi == EPI_RELUMASK;
+    const bool has_out2 = epi == EPI_GELU && p.out2 != nullptr;
+    const uint32_t vc = (uint32_t)(4 * h * (int)ldc + l31) * 4u;
+    const uint32_t va = (uint32_t)(4 * h * (int)ldaux + l31) * 4u;
+    const uint32_t va2 = (uint32_t)(4 * h * (int)ldaux2 + l31) * 4u;
+    const uint32_t vo2 = (uint32_t)(4 * h * (int)ldout2 + l31) * 4u;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        const int nb = nw + j * 32;
+        const int n = nb + l31;
+        if (CHECK && n >= p.N) continue;
+        const float bv = use_bias ? p.bias[n] : 0.f;
+#pragma unroll
+        for (int i = 0; i < WM; ++i) {
+            const int mb = mw + i * 32;
+            const int ml = mb + 4 * h;
+            float* cb = C + mb * ldc + nb;
+            float a[16], a2[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { a[r] = 0.f; a2[r] = 0.f; }
+            if (has_aux) {
+                const float* ab = p.aux + mb * ldaux + nb;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int ro = (r & 3) + 8 * (r >> 2);
+                    a[r] = (!CHECK || ml + ro < p.M) ? ld_off(ab + ro * ldaux, va) : 0.f;
+                }
+            }
+            if (has_aux2) {
+                const float* ab = p.aux2 + mb * ldaux2 + nb;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int ro = (r & 3) + 8 * (r >> 2);
+                    a2[r] = (!CHECK || ml + ro < p.M) ? ld_off(ab + ro * ldaux2, va2) : 0.f;
+                }
+            }
+            float v[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) v[r] = acc[i][j][r] + bv;
+            if (has_out2) {
+                float* ob = p.out2 + mb * ldout2 + nb;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int ro = (r & 3) + 8 * (r >> 2);
+                    if (!CHECK || ml + ro < p.M) at_off(ob + ro * ldout2, vo2) = v[r];
+                }
+            }
+            switch (epi) {
+                case EPI_RELU:
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) v[r] = epi_math<EPI_RELU>(v[r], a[r], a2[r]);
+                    break;
+                case EPI_GELU:
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) v[r] = epi_math<EPI_GELU>(v[r], a[r], a2[r]);
+                    break;
+                case EPI_TANH:
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) v[r] = epi_math<EPI_TANH>(v[r], a[r], a2[r]);
+                    break;
+                case EPI_ADD_AUX:
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) v[r] = epi_math<EPI_ADD_AUX>(v[r], a[r], a2[r]);
+                    break;
+                case EPI_MUL_GELU_GRAD:
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) v[r] = epi_math<EPI_MUL_GELU_GRAD>(v[r], a[r], a2[r]);
+                    break;
+                case EPI_ADD_AUX_RELUMASK:
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) v[r] = epi_math<EPI_ADD_AUX_RELUMASK>(v[r], a[r], a2[r]);
+                    break;
+                case EPI_RELUMASK:
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) v[r] = epi_math<EPI_RELUMASK>(v[r], a[r], a2[r]);
+                    break;
+                default: break;
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int ro = (r & 3) + 8 * (r >> 2);
+                if (!CHECK || ml + ro < p.M) at_off(cb + ro * ldc, vc) = v[r];
+            }
+        }
+    }
+}
+
 template <bool A_KC, bool B_KC, int WM, int NJ>
 __global__ __launch_bounds__(256, (WM * NJ <= 2) ? 4 : 2) void gemm_f32_kernel(const GemmParams p) {
     constexpr int BM = 64 * WM, BN = 64 * NJ;
@@ -464,6 +559,252 @@ __global__ __launch_bounds__(256, (WM * NJ <= 2) ? 4 : 2) void gemm_f32_kernel(c
 #undef NR_STORE
 }
 
+// =================================================================================================
+// bf16-input variant (v_mfma_f32_32x32x16_bf16, f32 accumulate): same operands in HBM (fp32), same
+// epilogues and split-K; the tiles are rounded to bf16 (RNE, v_cvt_pk_bf16_f32) on their way into LDS.
+// For the BERT-sized GEMMs whose parity bar is 1e-2.  Workgroup tile 128 x 128 x 32,
+// 4 waves 2x2, wave tile 64 x 64.  Both operands live in LDS k-contiguous as [row][32 + 8] bf16
+// (80-byte rows: 16-byte aligned and conflict-free for the ds_read_b128 of 8 consecutive k per lane);
+// reduction-major operands are transposed while being stored: a thread loads two consecutive k-rows
+// of the same 4 columns and writes 4 packed (k, k+1) pairs, lanes laid out so the 64 writes of one
+// instruction hit 64 different banks.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+constexpr int HB_LD = 40;            // bf16 per LDS row
+
+__device__ __forceinline__ uint32_t pack_bf16(float lo, float hi) {
+    const f32x2 v = {lo, hi};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2));
+}
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));   // staging registers as plain vector values (arrays of HIP's
+                                                            // float4 struct ended up in scratch in this kernel)
+__device__ __forceinline__ f32x4 ldg4(const void* p) { return *reinterpret_cast<const f32x4*>(p); }
+
+// k-contiguous 128 x 32 tile: thread loads f32x4 (row = t/8 + 32*i, k = (t%8)*4), zero past the row / k range
+struct LoaderKCH {
+    const float* ptr[4];
+    unsigned valid;
+    int c4;
+    const float* safe;
+    __device__ __forceinline__ void init(const float* base, int64_t ld, int row0, int nrows, int tid, const float* safe_) {
+        c4 = (tid & 7) * 4;
+        safe = safe_;
+        valid = 0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int r = row0 + (tid >> 3) + 32 * i;
+            const bool ok = r < nrows;
+            ptr[i] = base + (int64_t)(ok ? r : row0) * ld + c4;
+            if (ok) valid |= 1u << i;
+        }
+    }
+    __device__ __forceinline__ void load(f32x4& r0, f32x4& r1, f32x4& r2, f32x4& r3, int k0, int K) const {
+        const bool kok = k0 + c4 < K;
+        const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+        const bool o0 = kok && (valid & 1u), o1 = kok && (valid & 2u), o2 = kok && (valid & 4u), o3 = kok && (valid & 8u);
+        const f32x4 v0 = ldg4(o0 ? ptr[0] + k0 : safe), v1 = ldg4(o1 ? ptr[1] + k0 : safe);
+        const f32x4 v2 = ldg4(o2 ? ptr[2] + k0 : safe), v3 = ldg4(o3 ? ptr[3] + k0 : safe);
+        r0 = o0 ? v0 : z; r1 = o1 ? v1 : z; r2 = o2 ? v2 : z; r3 = o3 ? v3 : z;
+    }
+};
+
+// 16-byte chunk q (0..3) of row r sits at chunk q ^ hb_swz(r): rows 16..31 of every 32 swap their chunk pairs, which
+// is what makes the transposing stores below conflict-free; the b128 fragment reads stay conflict-free because the
+// 16 lanes of one read phase share the swizzle.
+__device__ __forceinline__ int hb_swz(int row) { return (row >> 3) & 2; }
+
+__device__ __forceinline__ void store_kc_bf16(uint32_t* lds, f32x4 r0, f32x4 r1, f32x4 r2, f32x4 r3, int tid) {
+    const int q = (tid & 7) >> 1, half = (tid & 1) * 2, row0 = tid >> 3;
+    const f32x4 r[4] = {r0, r1, r2, r3};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int row = row0 + 32 * i;
+        uint2 v;
+        v.x = pack_bf16(r[i][0], r[i][1]);
+        v.y = pack_bf16(r[i][2], r[i][3]);
+        *reinterpret_cast<uint2*>(lds + row * (HB_LD / 2) + 4 * (q ^ hb_swz(row)) + half) = v;
+    }
+}
+
+// reduction-major 32 (k) x 128 tile: wave w owns columns 32*w .. +31; lane = 8*c + a -> columns 32*w + 4*a .. +3 of the
+// k pair 8*i + c (k = 16*i + 2*c, +1), i = 0, 1: every wave instruction reads eight full 128-byte lines
+struct LoaderRMH {
+    const float* base;
+    int64_t ld;
+    uint32_t off;
+    bool cvalid;
+    int c;
+    const float* safe;
+    __device__ __forceinline__ void init(const float* base_, int64_t ld_, int col0, int ncols, int tid, const float* safe_) {
+        base = base_; ld = ld_; safe = safe_;
+        const int w = tid >> 6, lane = tid & 63, a = lane & 7;
+        c = lane >> 3;
+        const int col = col0 + 32 * w + 4 * a;
+        cvalid = col < ncols;
+        off = (uint32_t)(2 * c * (int)ld + (cvalid ? col : col0)) * 4u;
+    }
+    // r0/r1: rows k, k+1 of the k pair c; r2/r3: of the k pair 8 + c
+    __device__ __forceinline__ void load(f32x4& r0, f32x4& r1, f32x4& r2, f32x4& r3, int k0, int K) const {
+        const uint32_t rowb = (uint32_t)ld * 4u;
+        const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+        const char* kb0 = reinterpret_cast<const char*>(base + (int64_t)k0 * ld);             // uniform
+        const char* kb1 = reinterpret_cast<const char*>(base + (int64_t)(k0 + 16) * ld);
+        const char* sf = reinterpret_cast<const char*>(safe);
+        const int k = k0 + 2 * c;
+        const bool o0 = cvalid && k < K, o1 = cvalid && k + 1 < K, o2 = cvalid && k + 16 < K, o3 = cvalid && k + 17 < K;
+        const f32x4 v0 = ldg4(o0 ? kb0 + off : sf), v1 = ldg4(o1 ? kb0 + off + rowb : sf);
+        const f32x4 v2 = ldg4(o2 ? kb1 + off : sf), v3 = ldg4(o3 ? kb1 + off + rowb : sf);
+        r0 = o0 ? v0 : z; r1 = o1 ? v1 : z; r2 = o2 ? v2 : z; r3 = o3 ? v3 : z;
+    }
+};
+__device__ __forceinline__ void store_rm_bf16(uint32_t* lds, f32x4 r0, f32x4 r1, f32x4 r2, f32x4 r3, int tid) {
+    const int w = tid >> 6, lane = tid & 63, a = lane & 7, c = lane >> 3;
+    const int row = 32 * w + 4 * a;                       // rows row .. row+3 share bit 4 -> one swizzle
+    const int sw = hb_swz(row);
+    uint32_t* d0 = lds + row * (HB_LD / 2) + 4 * ((c >> 2) ^ sw) + (c & 3);
+    uint32_t* d1 = lds + row * (HB_LD / 2) + 4 * ((2 + (c >> 2)) ^ sw) + (c & 3);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        d0[j * (HB_LD / 2)] = pack_bf16(r0[j], r1[j]);
+        d1[j * (HB_LD / 2)] = pack_bf16(r2[j], r3[j]);
+    }
+}
+
+template <bool A_KC, bool B_KC>
+__global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const GemmParams p) {
+    constexpr int BM = 128, BN = 128, WM = 2, NJ = 2;
+    constexpr int STAGE = (BM + BN) * HB_LD / 2;          // dwords per pipeline stage
+    __shared__ __attribute__((aligned(16))) uint32_t smem[2 * STAGE];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wid >> 1, wc = wid & 1;
+    const int l31 = lane & 31, h = lane >> 5;
+
+    const int tiles_n = (p.N + BN - 1) / BN;
+    const int tiles_m = (p.M + BM - 1) / BM;
+    const int ntile = tiles_m * tiles_n;
+    int bid = blockIdx.x;
+    const int ks = bid / ntile;
+    bid -= ks * ntile;
+    {
+        const int q = ntile >> 3, r = ntile & 7, x = bid & 7, loc = bid >> 3;
+        bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + loc;
+    }
+    const int tm = bid / tiles_n, tn = bid - tm * tiles_n;
+    const int m0 = tm * BM, n0 = tn * BN;
+
+    const int kt_total = (p.K + BK - 1) / BK;
+    const int kt_per = (kt_total + p.ksplit - 1) / p.ksplit;
+    const int kt_begin = ks * kt_per;
+    const int kt_end = min(kt_total, kt_begin + kt_per);
+
+    f32x16 acc[WM][NJ];
+#pragma unroll
+    for (int i = 0; i < WM; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    f32x4 a0, a1, a2, a3, b0, b1, b2, b3;                 // the next k-tile on its way HBM -> LDS
+    LoaderKCH lkA, lkB; LoaderRMH lrA, lrB;
+    if (A_KC) lkA.init(p.A, p.lda, m0, p.M, tid, p.A); else lrA.init(p.A, p.lda, m0, p.M, tid, p.A);
+    if (B_KC) lkB.init(p.B, p.ldb, n0, p.N, tid, p.B); else lrB.init(p.B, p.ldb, n0, p.N, tid, p.B);
+
+    // bias gradient riding on dW (A reduction-major): exact fp32 column sums of the A tile taken from the
+    // staging registers before they are rounded; the 16 lanes that share a column meet in the epilogue
+    const bool do_csum = !A_KC && p.csum != nullptr && tn == 0;
+    f32x4 cs = {0.f, 0.f, 0.f, 0.f};                      // columns 32*w + 4*a .. +3, partial over this lane's k pairs
+
+    auto gload = [&](int kt) {
+        const int k0 = kt * BK;
+        if (A_KC) lkA.load(a0, a1, a2, a3, k0, p.K); else lrA.load(a0, a1, a2, a3, k0, p.K);
+        if (B_KC) lkB.load(b0, b1, b2, b3, k0, p.K); else lrB.load(b0, b1, b2, b3, k0, p.K);
+    };
+    auto lstore = [&](int buf) {
+        uint32_t* As = smem + buf * STAGE;
+        uint32_t* Bs = As + BM * HB_LD / 2;
+        if (A_KC) store_kc_bf16(As, a0, a1, a2, a3, tid);
+        else {
+            store_rm_bf16(As, a0, a1, a2, a3, tid);
+            if (do_csum) cs += (a0 + a1) + (a2 + a3);
+        }
+        if (B_KC) store_kc_bf16(Bs, b0, b1, b2, b3, tid); else store_rm_bf16(Bs, b0, b1, b2, b3, tid);
+    };
+
+    // two LDS stages, one barrier per k-tile: while tile kt is multiplied out of stage `cur`, tile kt+1 travels
+    // HBM -> registers -> stage cur^1 (last read before the previous barrier)
+    if (kt_begin < kt_end) {
+        gload(kt_begin);
+        lstore(0);
+    }
+    __syncthreads();
+    const int frag_sw = hb_swz(l31);                      // tile bases are multiples of 32 rows
+    int cur = 0;
+    for (int kt = kt_begin; kt < kt_end; ++kt) {
+        const bool more = kt + 1 < kt_end;
+        if (more) gload(kt + 1);
+        const uint32_t* As = smem + cur * STAGE;
+        const uint32_t* Bs = As + BM * HB_LD / 2;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const int q4 = 4 * ((2 * s + h) ^ frag_sw);
+            bf16x8 fa[WM], fb[NJ];
+#pragma unroll
+            for (int i = 0; i < WM; ++i)
+                fa[i] = *reinterpret_cast<const bf16x8*>(As + (wr * 64 + i * 32 + l31) * (HB_LD / 2) + q4);
+#pragma unroll
+            for (int j = 0; j < NJ; ++j)
+                fb[j] = *reinterpret_cast<const bf16x8*>(Bs + (wc * 64 + j * 32 + l31) * (HB_LD / 2) + q4);
+#pragma unroll
+            for (int i = 0; i < WM; ++i)
+#pragma unroll
+                for (int j = 0; j < NJ; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+        }
+        if (more) lstore(cur ^ 1);
+        __syncthreads();
+        cur ^= 1;
+    }
+    if (do_csum) {
+        float* dst = p.ksplit > 1 ? p.csum_part + (int64_t)ks * p.M : p.csum;
+        const int a = lane & 7, c = lane >> 3;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float v = cs[j];
+            v += __shfl_xor(v, 8);
+            v += __shfl_xor(v, 16);
+            v += __shfl_xor(v, 32);
+            const int col = m0 + 32 * wid + 4 * a + j;
+            if (c == 0 && col < p.M) dst[col] = v;
+        }
+    }
+
+    const bool partial = p.ksplit > 1;
+    float* Cout = partial ? p.C + (int64_t)ks * p.split_stride : p.C;
+    const int mw = m0 + wr * 64, nw = n0 + wc * 64;
+    const bool full = (mw + 64 <= p.M) && (nw + 64 <= p.N);
+    const bool ub = !partial && p.bias != nullptr;
+    const int epi = partial ? EPI_NONE : p.epi;
+    if (full) store_block_rt<WM, NJ, false>(acc, Cout, mw, nw, l31, h, ub, epi, p);
+    else      store_block_rt<WM, NJ, true>(acc, Cout, mw, nw, l31, h, ub, epi, p);
+}
+
+template <bool A_KC, bool B_KC>
+static int launch_bf16(const GemmParams& p, hipStream_t s) {
+    const int tiles = cdiv(p.M, 128) * cdiv(p.N, 128);
+    hipLaunchKernelGGL((gemm_bf16_kernel<A_KC, B_KC>), dim3(tiles * p.ksplit), dim3(256), 0, s, p);
+    return check_launch("gemm_bf16");
+}
+
+static std::atomic<int> g_gemm_compute{0};
+void set_gemm_compute(int mode) { g_gemm_compute.store(mode); }
+int get_gemm_compute() { return g_gemm_compute.load(); }
+
 // sum split-K slabs (fixed order -> deterministic), add bias, apply epilogue
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmParams p, const float* __restrict__ slabs) {
     const int64_t total = (int64_t)p.M * p.N;
@@ -587,9 +928,17 @@ int gemm_f32(GemmParams p, bool a_kc, bool b_kc, float* workspace, size_t ws_byt
         slabs = workspace;
         q.C = slabs; q.ldc = p.N; q.split_stride = (int64_t)p.M * p.N;
     }
+    int rc;
+    // bf16-input matrix cores when the caller asked for them (nr_set_gemm_compute(1)) and the product is big enough
+    // to matter; conv views and small products stay on the exact fp32 kernel
+    const bool half = g_gemm_compute.load() == 1 && !p.conv_on && p.M >= 128 && p.N >= 128 && p.K >= 128;
+    if (half) {
+        if (a_kc && b_kc)        rc = launch_bf16<true, true>(q, s);
+        else if (a_kc && !b_kc)  rc = launch_bf16<true, false>(q, s);
+        else                     rc = launch_bf16<false, false>(q, s);
+    } else {
     // BN=128 only when it wastes no more columns than BN=64
     const bool wide = (cdiv(p.N, 128) * 128 == cdiv(p.N, 64) * 64) && p.N >= 128;
-    int rc;
     // few 128-row tiles (the user tower: 1600 history rows) leave most CUs idle: halve the tile
     // ... and so does a short, narrow product (N <= 320, K <= 512: out-proj / pooling projection at 300-d, +5-9 %):
     // ten k-tiles per workgroup are mostly prologue/epilogue, which 7 resident waves per SIMD overlap better
@@ -602,6 +951,7 @@ int gemm_f32(GemmParams p, bool a_kc, bool b_kc, float* workspace, size_t ws_byt
         else rc = wide ? launch_tiled<false, false, 2, 2>(q, s) : launch_tiled<false, false, 2, 1>(q, s);
     }
     else { set_error("gemm: layout (A red-major, B k-contig) not built"); return NR_ERR_UNSUPPORTED; }
+    }
     if (rc != NR_OK) return rc;
     if (p.ksplit > 1) {
         GemmParams r = p;

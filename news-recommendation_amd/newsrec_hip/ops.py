@@ -678,3 +678,17 @@ def prof_read(family):
     ms, n, work = C.c_double(), C.c_int64(), C.c_double()
     check(lib().nr_prof_read(family, C.byref(ms), C.byref(n), C.byref(work)), "nr_prof_read")
     return ms.value, n.value, work.value
+
+
+# ----------------------------------------------------------------------------- GEMM precision
+def set_gemm_compute(mode):
+    """"fp32" (default: exact f32 matrix cores) or "bf16" (operands rounded to bf16 in LDS, f32 accumulate, large
+    non-conv products only; the 1e-2 parity bar of SURVEY §8 a7).  Process-wide and sticky."""
+    modes = {"fp32": 0, "bf16": 1}
+    if mode not in modes:
+        raise NewsrecError(f"set_gemm_compute: unknown mode {mode!r} (fp32 | bf16)")
+    check(lib().nr_set_gemm_compute(modes[mode]), "nr_set_gemm_compute")
+
+
+def get_gemm_compute():
+    return ("fp32", "bf16")[lib().nr_get_gemm_compute()]

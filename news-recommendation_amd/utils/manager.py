@@ -75,6 +75,9 @@ _FLAGS = [
     (("--debug",), "debug", dict(action="store_true", default=False)),
     # extensions (not in the reference)
     (("--synthetic-plm",), "synthetic_plm", dict(action="store_true", default=False, help="random token table instead of a PLM dir")),
+    (("--bf16",), "bf16", dict(action="store_true", default=False,
+                               help="bf16-operand matrix cores (f32 accumulate, tensors stay fp32) for every large dense product: "
+                                    "the 1e-2-parity build meant for -ne bert; default is exact fp32")),
     (("--host-assembly",), "host_assembly", dict(action="store_true", default=False,
                                                  help="ship token ids/masks in every batch like the reference (default on a GPU: "
                                                       "batches carry news indices only and the token rows are gathered on the device)")),
@@ -160,6 +163,9 @@ class Manager():
             self.rank = 0
             if self.device != "cpu":
                 torch.cuda.set_device(self.device)
+        if self.device != "cpu":
+            from newsrec_hip import ops
+            ops.set_gemm_compute("bf16" if getattr(self, "bf16", False) else "fp32")
 
     def barrier(self):
         if self.distributed:

@@ -100,6 +100,59 @@ def test_linear_backward(ops, R, K, N):
     assert relerr(db, dy.sum(0)) < FP32_TOL
 
 
+
+# ------------------------------------------------------------------ bf16-operand matrix cores
+@pytest.fixture
+def bf16_gemm(ops):
+    ops.set_gemm_compute("bf16")
+    assert ops.get_gemm_compute() == "bf16"
+    yield ops
+    ops.set_gemm_compute("fp32")
+
+
+def _rb(t):
+    """what the kernel multiplies: the operand rounded to bf16 (round to nearest even), products and sums in f32"""
+    return t.to(torch.bfloat16).to(torch.float32)
+
+
+@pytest.mark.parametrize("R,K,N", [(14080, 768, 768), (1000, 300, 900), (4100, 3072, 768), (130, 132, 260), (640, 768, 2304)])
+def test_bf16_gemm_forward_backward(bf16_gemm, R, K, N):
+    """exact statement of the bf16 build: C = bf16(A) . bf16(B)^T with f32 accumulation — checked to the fp32 bar
+    against that expression (so only the summation order differs), and to the 1e-2 bar against the fp32 product.
+    Ragged M / N / K, split-K dW with the fused bias gradient, and every epilogue the layers use."""
+    ops = bf16_gemm
+    g = G(31)
+    x = torch.randn(R, K, generator=g)
+    w = torch.randn(N, K, generator=g) / math.sqrt(K)
+    b = torch.randn(N, generator=g) * 0.1
+    dy = torch.randn(R, N, generator=g)
+    aux = torch.randn(R, K, generator=g)
+    ref = _rb(x) @ _rb(w).t() + b
+    z = torch.empty(R, N, device="cuda")
+    y = ops.linear_fwd(x.cuda(), w.cuda(), b.cuda(), "gelu", z)
+    assert relerr(z, ref) < FP32_TOL and relerr(y, F.gelu(ref)) < FP32_TOL
+    assert relerr(z, F.linear(x, w, b)) < 1e-2
+    y = ops.linear_fwd(x.cuda(), w.cuda(), b.cuda(), "none", None)
+    assert relerr(y, ref) < FP32_TOL
+    dx = ops.linear_bwd_input(dy.cuda(), w.cuda())
+    assert relerr(dx, _rb(dy) @ _rb(w)) < FP32_TOL and relerr(dx, dy @ w) < 1e-2
+    dx1 = ops.linear_bwd_input(dy.cuda(), w.cuda(), 1, aux.cuda())
+    assert relerr(dx1, _rb(dy) @ _rb(w) + aux) < FP32_TOL
+    dw, db = ops.linear_bwd_weight(dy.cuda(), x.cuda())
+    assert relerr(dw, _rb(dy).t() @ _rb(x)) < FP32_TOL and relerr(dw, dy.t() @ x) < 1e-2
+    assert relerr(db, dy.sum(0)) < FP32_TOL                     # the bias gradient is summed from the fp32 tile
+
+
+def test_bf16_mode_leaves_small_and_conv_products_exact(bf16_gemm):
+    ops = bf16_gemm
+    g = G(32)
+    x = torch.randn(96, 64, generator=g)
+    w = torch.randn(100, 64, generator=g)
+    assert relerr(ops.linear_fwd(x.cuda(), w.cuda(), None, "none", None), x @ w.t()) < FP32_TOL
+    with pytest.raises(Exception):
+        ops.set_gemm_compute("fp8")
+
+
 def test_linear_autograd_module(ops):
     g = G(5)
     x = torch.randn(4, 9, 48, generator=g)

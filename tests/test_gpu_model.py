@@ -173,6 +173,48 @@ def test_nrms_train_step_vs_oracle():
         assert relerr(p_, P[n]) < 1e-5, n
 
 
+def test_bert_bf16_build_vs_oracle():
+    """SURVEY §8 a7's bf16-MFMA build: AllBertNewsEncoder (hidden 256, 3 layers, 4 heads) + attention user encoder with
+    every large dense product on the bf16-operand kernel, against the fp32 oracle.  The bar north_star states for
+    bf16 is 1e-2 (norm-wise, on the vectors, the loss and every weight gradient)."""
+    from newsrec_hip import ops
+    meta = dict(V=2000, E=256, D=256, H=4, T=32, L=10, K=4, B=4, Nn=300, NL=3)
+    model, mgr = build_model(meta, "bert", "attn")
+    g = torch.Generator().manual_seed(41)
+    ids, msk = synth_news_table(g, meta["Nn"], meta["T"], meta["V"])
+    X = synth_batch(g, meta["B"], meta["K"] + 1, meta["L"], meta["Nn"], ids, msk)
+    P = {k: v.detach().clone().requires_grad_(True) for k, v in model.state_dict().items()}
+    loss_ref, aux = O.train_forward(P, "bert", "attn", X, head_num=meta["H"])
+    loss_ref.backward()
+    model = model.cuda().eval()
+    ops.set_gemm_compute("bf16")
+    try:
+        _, cdd = model._encode_news(X)
+        user = model._encode_user(X)
+        loss = model(X)
+        loss.backward()
+        torch.cuda.synchronize()
+    finally:
+        ops.set_gemm_compute("fp32")
+    assert relerr(cdd, aux["cdd"]) < 1e-2
+    assert relerr(user, aux["user"]) < 1e-2
+    assert abs(loss.item() - loss_ref.item()) < 1e-2 * abs(loss_ref.item())
+    # gradients: 1e-2 norm-wise per tensor, with an absolute floor for tensors whose whole gradient sits five orders
+    # below the largest one (user_query at random init: |g| ~ 1e-6 vs 0.1; measured 0.2-1.0e-2 on all the others)
+    gscale = max(float(P[n].grad.abs().max()) for n, _ in model.named_parameters() if P[n].grad is not None)
+    for n, p_ in model.named_parameters():
+        rg = P[n].grad
+        if rg is None:
+            continue
+        err = (p_.grad.cpu() - rg).norm().item()
+        assert err <= 1e-2 * rg.norm().item() + 1e-5 * gscale * rg.numel() ** 0.5, (n, err, rg.norm().item())
+    # the same model in fp32 mode stays at the fp32 bar: the switch really selects the kernel
+    model.zero_grad()
+    loss32 = model(X)
+    assert abs(loss32.item() - loss_ref.item()) < FP32_TOL * abs(loss_ref.item())
+    assert loss32.item() != loss.item()
+
+
 def test_cpu_tensors_fail_loudly():
     from newsrec_hip import ops, NewsrecError
     with pytest.raises(NewsrecError):

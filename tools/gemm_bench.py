@@ -16,6 +16,10 @@ def timeit(fn, n=20):
 
 R = int(sys.argv[1]) if len(sys.argv) > 1 else 56320
 shapes = [("qkv", 300, 900), ("outproj", 300, 300), ("ffn1", 300, 1200), ("ffn2", 1200, 300), ("d768", 768, 768), ("ffn1_768", 768, 3072)]
+if len(sys.argv) > 2:                      # second argument: fp32 | bf16 (nr_set_gemm_compute); bf16 runs the BERT-base shapes
+    ops.set_gemm_compute(sys.argv[2])
+    if sys.argv[2] == "bf16":
+        shapes = [("qkv_768", 768, 2304), ("d768", 768, 768), ("ffn1_768", 768, 3072), ("ffn2_768", 3072, 768), ("ffn1", 300, 1200)]
 for name, K, N in shapes:
     x = torch.randn(R, K, device="cuda"); w = torch.randn(N, K, device="cuda") / K ** 0.5; b = torch.randn(N, device="cuda")
     dy = torch.randn(R, N, device="cuda"); aux = torch.randn(R, K, device="cuda")
