@@ -6,6 +6,7 @@
 #include "../../include/newsrec_hip.h"
 
 #include <stdarg.h>
+#include <cstdlib>
 #include <mutex>
 #include <vector>
 
@@ -520,6 +521,7 @@ int nr_tfm_layer_bwd_f32(const float* dy, const float* x, const int64_t* mask, i
 }
 
 // ------------------------------------------------------------------------------------ GRU user encoder
+static bool g_gru_per_step = getenv("NR_GRU_PER_STEP") != nullptr;   // tests/bench: force the per-step path
 int nr_gru_fwd_f32(const float* x, const int64_t* mask, const float* w_ih, const float* w_hh, const float* b_ih, const float* b_hh,
                    int64_t B, int64_t L, int64_t Din, int64_t H, float* gi, float* gh, float* hall, float* gates, int32_t* lens,
                    void* ws, size_t ws_bytes, void* stream) {
@@ -531,6 +533,13 @@ int nr_gru_fwd_f32(const float* x, const int64_t* mask, const float* w_ih, const
     if (hipMemsetAsync(hall, 0, (size_t)B * H * sizeof(float), s) != hipSuccess) { set_error("gru_fwd: memset failed"); return NR_ERR_LAUNCH; }
     // input half of every step in one GEMM: GI[b*L+t, :] = x[b,t,:] W_ih^T + b_ih
     if (int rc = linear_fwd(x, Din, w_ih, b_ih, B * L, Din, 3 * H, EPI_NONE, gi, nullptr, s)) return rc;
+    // the recurrence: one persistent launch when the shape allows it (the counter lives at the head of the workspace) ...
+    if (ws && ws_bytes >= 256 && gru_seq_fwd_supported((int)B, (int)H) && !g_gru_per_step) {
+        const int rc = gru_seq_fwd(gi, w_hh, b_hh, lens, hall, gates, (int)B, (int)L, (int)H, (unsigned*)ws, s);
+        if (rc != NR_ERR_UNSUPPORTED) return rc;
+    }
+    // ... else one skinny GEMM + one gate kernel per step
+    if (ws && ws_bytes >= 256) { ws = (char*)ws + 256; ws_bytes -= 256; }
     for (int t = 0; t < (int)L; ++t) {
         const float* hp = hall + (size_t)t * B * H;
         if (int rc = linear_fwd(hp, H, w_hh, b_hh, B, H, 3 * H, EPI_NONE, gh, nullptr, s, (float*)ws, ws_bytes)) return rc;
@@ -540,7 +549,7 @@ int nr_gru_fwd_f32(const float* x, const int64_t* mask, const float* w_ih, const
     return NR_OK;
 }
 
-size_t nr_gru_fwd_ws_bytes(int64_t B, int64_t H) { return skinny_ws_bytes(B, 3 * H, H); }
+size_t nr_gru_fwd_ws_bytes(int64_t B, int64_t H) { return skinny_ws_bytes(B, 3 * H, H) + 256; }
 
 size_t nr_gru_bwd_ws_bytes(int64_t B, int64_t L, int64_t Din, int64_t H) {
     return 2 * pad256((size_t)B * L * 3 * H) + 3 * pad256((size_t)B * H) +

@@ -76,6 +76,160 @@ __global__ __launch_bounds__(256) void gru_gate_bwd_kernel(const float* __restri
     }
 }
 
+// ---- the whole forward recurrence in ONE persistent launch -----------------------------------
+// The per-step pair (GEMM + gate kernel) is latency-bound: 100 launches of ~7.5 us for L = 50.  Here workgroup w owns
+// GRU_U = 10 hidden units for all L steps.  Its slice of W_hh (30 rows: r, z, n of the 10 units = 30 of the 32 columns
+// of one MFMA tile) stays in registers for the whole kernel, split over 12 waves by k; per step a wave multiplies the
+// [B, k-slice] part of h_{t-1} (read from HBM/L2, where the other workgroups published it) into a 32x32 partial, the
+// partials meet in LDS, 320 threads apply the gates and publish h_t, and all workgroups meet at a grid barrier
+// (agent-scope release -> atomic counter -> acquire; cooperative launch, so co-residency is checked by the runtime,
+// and the spin is bounded so that a lost workgroup ends the kernel instead of hanging the GPU).
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+constexpr int GRU_U = 10;
+constexpr int GRU_WAVES = 12;
+constexpr int GRU_NS = 48;           // MFMAs per wave and batch tile at most: k-slice <= 96, H <= 1152
+constexpr int GRU_PLD = 33;
+
+// The state crosses workgroups (and XCDs, each with its own L2) through agent-scope relaxed atomics: stores write
+// through to the coherence point, loads bypass the non-coherent caches.  A release/acquire fence pair instead costs an
+// L2 write-back + invalidate per wave and step (measured: 24 us per step, slower than the two launches it replaces).
+__device__ __forceinline__ void st_agent(float* p, float v) {
+    __hip_atomic_store(reinterpret_cast<unsigned*>(p), __builtin_bit_cast(unsigned, v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ float ld_agent(const float* p) {
+    return __builtin_bit_cast(float, __hip_atomic_load(reinterpret_cast<const unsigned*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+}
+__device__ __forceinline__ void ld_agent2(const float* p, float& a, float& b) {          // p 8-byte aligned
+    const unsigned long long v = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    a = __builtin_bit_cast(float, (unsigned)(v & 0xffffffffu));
+    b = __builtin_bit_cast(float, (unsigned)(v >> 32));
+}
+
+__device__ __forceinline__ void gru_grid_sync(unsigned* counter, unsigned target) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this wave's state stores have reached the coherence point
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        unsigned spins = 0;
+        while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+            if (++spins > (1u << 22)) {                    // ~seconds: give up loudly rather than hang
+                __hip_atomic_store(counter + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                break;
+            }
+            __builtin_amdgcn_s_sleep(1);
+        }
+    }
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(64 * GRU_WAVES) void gru_seq_fwd_kernel(const float* __restrict__ gi, const float* __restrict__ w_hh,
+                                                                    const float* __restrict__ b_hh, const int* __restrict__ lens,
+                                                                    float* hall, float* __restrict__ gates, int B, int L, int H,
+                                                                    int KS, unsigned* counter) {
+    __shared__ float part[GRU_WAVES][32 * GRU_PLD];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int q = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, hh = lane >> 5;
+    const int j0 = blockIdx.x * GRU_U;
+    const int kq0 = q * KS, nu = KS / 8;
+
+    // this lane's column of the weight tile: gate = n / 10, unit = n % 10 (columns 30, 31 are padding)
+    float w[GRU_NS];
+    {
+        const int gate = l31 / GRU_U, unit = l31 - gate * GRU_U, j = j0 + unit;
+        const bool wvalid = l31 < 3 * GRU_U && j < H;
+        const float* wrow = w_hh + (int64_t)(wvalid ? gate * H + j : 0) * H;
+#pragma unroll
+        for (int u = 0; u < GRU_NS / 4; ++u) {
+            const int k = kq0 + 8 * u + 4 * hh;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (wvalid && u < nu && k < H) v = *reinterpret_cast<const f32x4*>(wrow + k);
+            w[4 * u] = v[0]; w[4 * u + 1] = v[1]; w[4 * u + 2] = v[2]; w[4 * u + 3] = v[3];
+        }
+    }
+    const int btiles = (B + 31) / 32;
+    for (int t = 0; t < L; ++t) {
+        const float* hp = hall + (size_t)t * B * H;
+        float* hn = hall + (size_t)(t + 1) * B * H;
+        for (int bt = 0; bt < btiles; ++bt) {
+            const int b = bt * 32 + l31;
+            const float* hrow = hp + (int64_t)(b < B ? b : 0) * H;
+            f32x16 acc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+            for (int u = 0; u < GRU_NS / 4; ++u) {
+                if (u < nu) {                              // uniform
+                    const int k = kq0 + 8 * u + 4 * hh;
+                    f32x4 a = {0.f, 0.f, 0.f, 0.f};
+                    if (b < B && k < H) {
+                        float a0, a1, a2, a3;
+                        ld_agent2(hrow + k, a0, a1);
+                        ld_agent2(hrow + k + 2, a2, a3);
+                        a[0] = a0; a[1] = a1; a[2] = a2; a[3] = a3;
+                    }
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[0], w[4 * u], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[1], w[4 * u + 1], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[2], w[4 * u + 2], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[3], w[4 * u + 3], acc, 0, 0, 0);
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) part[q][((r & 3) + 8 * (r >> 2) + 4 * hh) * GRU_PLD + l31] = acc[r];
+            __syncthreads();
+            if (tid < 32 * GRU_U) {
+                const int bb = tid / GRU_U, unit = tid - bb * GRU_U;
+                const int b2 = bt * 32 + bb, j = j0 + unit;
+                if (b2 < B && j < H) {
+                    float g3[3];
+#pragma unroll
+                    for (int g = 0; g < 3; ++g) {
+                        float v = 0.f;
+#pragma unroll
+                        for (int qq = 0; qq < GRU_WAVES; ++qq) v += part[qq][bb * GRU_PLD + g * GRU_U + unit];
+                        g3[g] = v + b_hh[g * H + j];
+                    }
+                    const float hprev = ld_agent(hp + (int64_t)b2 * H + j);
+                    float hnext = hprev;
+                    if (t < lens[b2]) {
+                        const float* gib = gi + ((int64_t)b2 * L + t) * 3 * H;
+                        const float r = sigmoid_f(gib[j] + g3[0]);
+                        const float z = sigmoid_f(gib[H + j] + g3[1]);
+                        const float n = tanhf(gib[2 * H + j] + r * g3[2]);
+                        hnext = (1.0f - z) * n + z * hprev;
+                        if (gates) {
+                            float* sv = gates + ((size_t)t * B + b2) * 4 * H;
+                            sv[j] = r; sv[H + j] = z; sv[2 * H + j] = n; sv[3 * H + j] = g3[2];
+                        }
+                    }
+                    st_agent(hn + (int64_t)b2 * H + j, hnext);
+                }
+            }
+            __syncthreads();
+        }
+        if (t + 1 < L) gru_grid_sync(counter, (unsigned)(t + 1) * gridDim.x);
+    }
+}
+
+bool gru_seq_fwd_supported(int B, int H) { return H % 4 == 0 && H <= 12 * 2 * GRU_NS && B >= 1 && B <= 1024; }
+
+// counter: 2 unsigned in device memory (arrivals, timeout flag), zeroed here
+int gru_seq_fwd(const float* gi, const float* w_hh, const float* b_hh, const int* lens, float* hall, float* gates, int B, int L, int H,
+                unsigned* counter, hipStream_t s) {
+    if (hipMemsetAsync(counter, 0, 2 * sizeof(unsigned), s) != hipSuccess) { set_error("gru_seq_fwd: memset failed"); return NR_ERR_LAUNCH; }
+    int KS = ((H + GRU_WAVES - 1) / GRU_WAVES + 7) / 8 * 8;
+    const int grid = cdiv(H, GRU_U);
+    void* args[] = {(void*)&gi, (void*)&w_hh, (void*)&b_hh, (void*)&lens, (void*)&hall, (void*)&gates, (void*)&B, (void*)&L, (void*)&H,
+                    (void*)&KS, (void*)&counter};
+    ProfScope prof(FAM_GEMM, s, 2.0 * B * H * 3.0 * H * L);
+    if (hipLaunchCooperativeKernel((const void*)gru_seq_fwd_kernel, dim3(grid), dim3(64 * GRU_WAVES), args, 0, s) != hipSuccess) {
+        (void)hipGetLastError();
+        return NR_ERR_UNSUPPORTED;                         // the caller falls back to the per-step path
+    }
+    return check_launch("gru_seq_fwd");
+}
+
 int gru_lens(const int64_t* mask, int* lens, int B, int L, hipStream_t s) {
     hipLaunchKernelGGL(gru_lens_kernel, dim3(cdiv(B, 256)), dim3(256), 0, s, mask, lens, B, L);
     return check_launch("gru_lens");

@@ -31,7 +31,10 @@ int seq_reduce(const float* x, const float* table, const int64_t* idx, int64_t n
 int seq_broadcast(const float* dout, float* dx, int64_t nseq, int S, int D, float scale, hipStream_t s);
 
 
-// GRU recurrence halves (gru.hip)
+// GRU recurrence (gru.hip): one persistent launch for the whole forward, or the per-step halves
+bool gru_seq_fwd_supported(int B, int H);
+int gru_seq_fwd(const float* gi, const float* w_hh, const float* b_hh, const int* lens, float* hall, float* gates, int B, int L, int H,
+                unsigned* counter, hipStream_t s);
 int gru_lens(const int64_t* mask, int* lens, int B, int L, hipStream_t s);
 int gru_gate_fwd(const float* gi, const float* gh, const float* hprev, const int* lens, float* hnext, float* saved, int B, int L,
                  int H, int t, hipStream_t s);

@@ -431,7 +431,7 @@ def test_adam_matches_torch(ops):
 
 
 # ------------------------------------------------------------------ GRU user encoder (final state of a packed batch)
-@pytest.mark.parametrize("B,L,D", [(32, 50, 300), (8, 50, 768), (5, 7, 24), (200, 50, 96), (1, 1, 8)])
+@pytest.mark.parametrize("B,L,D", [(32, 50, 300), (8, 50, 768), (5, 7, 24), (200, 50, 96), (1, 1, 8), (6, 9, 26)])
 def test_gru_final_state(ops, B, L, D):
     """vs the oracle's explicit cell loop AND torch.nn.GRU over pack_padded_sequence on CPU (the reference's
     call, encoder.py:226-232): user vector, input gradient and the four parameter gradients."""
