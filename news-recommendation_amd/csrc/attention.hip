@@ -1,5 +1,5 @@
-// Multi-head self-attention over short sequences (titles S=32, histories S=50; S <= 64),
-// one wave per (sequence, head).  The S x S score tile is tiny (<= 16 KiB), so the whole
+// Multi-head self-attention over short sequences (titles S=32, histories S=50, title+abstract S=96; S <= 128),
+// one wave (two for S > 64) per (sequence, head).  The S x S score tile is tiny (<= 16 KiB), so the whole
 // head lives in LDS/registers: lane i owns query row i (fwd, bwd phase A) or key row j
 // (bwd phase B).  Score arithmetic follows the reference literally:
 //   x_ij = fl32( fl32(q_i . k_j) / sqrt(dh) ) + (1 - mask_j) * (-1e5)      (attention.py:87-90)
@@ -15,16 +15,16 @@ namespace nr {
 // cooperative [S, dh] tile copy global(row stride ld) -> LDS rows of DHP+1 floats (zero padded)
 // LDS row stride LDS_LD: DHP+1 (odd: conflict-free when lane i reads row i) or DHP (16-B aligned
 // rows for broadcast float4 reads of K/V)
-template <int DHP, int LDS_LD>
+template <int DHP, int LDS_LD, int NT = 64>
 __device__ __forceinline__ void tile_to_lds(float* lds, const float* __restrict__ g, int64_t ld, int S, int dh, int lane) {
-    for (int idx = lane; idx < S * DHP; idx += 64) {
+    for (int idx = lane; idx < S * DHP; idx += NT) {
         const int r = idx / DHP, d = idx - r * DHP;
         lds[r * LDS_LD + d] = (d < dh) ? g[(int64_t)r * ld + d] : 0.f;
     }
 }
-template <int DHP, int LDS_LD>
+template <int DHP, int LDS_LD, int NT = 64>
 __device__ __forceinline__ void lds_to_tile(float* __restrict__ g, int64_t ld, const float* lds, int S, int dh, int lane) {
-    for (int idx = lane; idx < S * dh; idx += 64) {
+    for (int idx = lane; idx < S * dh; idx += NT) {
         const int r = idx / dh, d = idx - r * dh;
         g[(int64_t)r * ld + d] = lds[r * LDS_LD + d];
     }
@@ -57,8 +57,8 @@ __device__ __forceinline__ float keep_scale(const DropoutCfg& dc, uint32_t thr, 
     return philox_pick(rn, (int)(idx & 3)) >= thr ? scale : 0.f;
 }
 
-template <int DHP>
-__global__ __launch_bounds__(64) void mhsa_fwd_kernel(const float* __restrict__ qkv, const int64_t* __restrict__ mask,
+template <int DHP, int NT>
+__global__ __launch_bounds__(NT) void mhsa_fwd_kernel(const float* __restrict__ qkv, const int64_t* __restrict__ mask,
                                                       float* __restrict__ ctx, float* __restrict__ row_max,
                                                       float* __restrict__ row_sum, int S, int H, int dh, DropoutCfg dc) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -72,9 +72,9 @@ __global__ __launch_bounds__(64) void mhsa_fwd_kernel(const float* __restrict__ 
     const int A = H * dh;
     const int64_t ld = 3 * (int64_t)A;
     const float* base = qkv + (int64_t)n * S * ld + h * dh;
-    tile_to_lds<DHP, LD>(Qs, base, ld, S, dh, lane);
-    tile_to_lds<DHP, DHP>(Ks, base + A, ld, S, dh, lane);
-    tile_to_lds<DHP, DHP>(Vs, base + 2 * A, ld, S, dh, lane);
+    tile_to_lds<DHP, LD, NT>(Qs, base, ld, S, dh, lane);
+    tile_to_lds<DHP, DHP, NT>(Ks, base + A, ld, S, dh, lane);
+    tile_to_lds<DHP, DHP, NT>(Vs, base + 2 * A, ld, S, dh, lane);
     __syncthreads();
 
     const int i = lane;
@@ -120,12 +120,12 @@ __global__ __launch_bounds__(64) void mhsa_fwd_kernel(const float* __restrict__ 
         for (int d = 0; d < DHP; ++d) Qs[i * LD + d] = o[d];   // row i of Qs is only read by lane i
     }
     __syncthreads();
-    lds_to_tile<DHP, LD>(ctx + (int64_t)n * S * A + h * dh, A, Qs, S, dh, lane);
+    lds_to_tile<DHP, LD, NT>(ctx + (int64_t)n * S * A + h * dh, A, Qs, S, dh, lane);
 }
 
 // backward: dqkv[:, q|k|v block of head h] from dctx; recomputes p from (qkv, row_max, row_sum)
-template <int DHP>
-__global__ __launch_bounds__(64) void mhsa_bwd_kernel(const float* __restrict__ qkv, const int64_t* __restrict__ mask,
+template <int DHP, int NT>
+__global__ __launch_bounds__(NT) void mhsa_bwd_kernel(const float* __restrict__ qkv, const int64_t* __restrict__ mask,
                                                       const float* __restrict__ ctx, const float* __restrict__ dctx,
                                                       const float* __restrict__ row_max, const float* __restrict__ row_sum,
                                                       float* __restrict__ dqkv, int S, int H, int dh, DropoutCfg dc) {
@@ -143,10 +143,10 @@ __global__ __launch_bounds__(64) void mhsa_bwd_kernel(const float* __restrict__ 
     const int A = H * dh;
     const int64_t ld = 3 * (int64_t)A;
     const float* base = qkv + (int64_t)n * S * ld + h * dh;
-    tile_to_lds<DHP, LD>(Qs, base, ld, S, dh, lane);
-    tile_to_lds<DHP, DHP>(Ks, base + A, ld, S, dh, lane);
-    tile_to_lds<DHP, DHP>(Vs, base + 2 * A, ld, S, dh, lane);
-    tile_to_lds<DHP, LD>(Gs, dctx + (int64_t)n * S * A + h * dh, A, S, dh, lane);
+    tile_to_lds<DHP, LD, NT>(Qs, base, ld, S, dh, lane);
+    tile_to_lds<DHP, DHP, NT>(Ks, base + A, ld, S, dh, lane);
+    tile_to_lds<DHP, DHP, NT>(Vs, base + 2 * A, ld, S, dh, lane);
+    tile_to_lds<DHP, LD, NT>(Gs, dctx + (int64_t)n * S * A + h * dh, A, S, dh, lane);
     __syncthreads();
 
     const bool live = lane < S;
@@ -189,7 +189,7 @@ __global__ __launch_bounds__(64) void mhsa_bwd_kernel(const float* __restrict__ 
     }
     __syncthreads();
     float* dbase = dqkv + (int64_t)n * S * ld + h * dh;
-    lds_to_tile<DHP, LD>(dbase, ld, Ts, S, dh, lane);
+    lds_to_tile<DHP, LD, NT>(dbase, ld, Ts, S, dh, lane);
     // ---- phase B: lane = key row j
     {
         const int j = lane;
@@ -214,10 +214,11 @@ __global__ __launch_bounds__(64) void mhsa_bwd_kernel(const float* __restrict__ 
         }
     }
     __syncthreads();
-    lds_to_tile<DHP, LD>(dbase + A, ld, Qs, S, dh, lane);
-    lds_to_tile<DHP, LD>(dbase + 2 * A, ld, Gs, S, dh, lane);
+    lds_to_tile<DHP, LD, NT>(dbase + A, ld, Qs, S, dh, lane);
+    lds_to_tile<DHP, LD, NT>(dbase + 2 * A, ld, Gs, S, dh, lane);
 }
 
+constexpr size_t MHSA_LDS_MAX = 160 * 1024;    // one workgroup may take the CU's whole LDS
 static int pick_dhp(int dh) { return dh <= 32 ? 32 : (dh <= 64 ? 64 : (dh <= 128 ? 128 : 0)); }
 
 int mhsa_fwd(const float* qkv, const int64_t* mask, float* ctx, float* row_max, float* row_sum, int64_t N, int S, int H,
@@ -227,19 +228,21 @@ int mhsa_fwd(const float* qkv, const int64_t* mask, float* ctx, float* row_max, 
         ProfScope prof(FAM_ATTN, s, 4.0 * N * H * S * S * dh);
         return mhsa_fwd_mfma(qkv, mask, ctx, row_max, row_sum, N, S, H, dh, dc, s);
     }
-    NR_UNSUPPORTED(S > 64 || S < 1, "mhsa: sequence length %d not in [1,64]", S);
+    NR_UNSUPPORTED(S > 128 || S < 1, "mhsa: sequence length %d not in [1,128]", S);
     const int dhp = pick_dhp(dh);
     NR_UNSUPPORTED(dhp == 0, "mhsa: head dim %d > 128", dh);
-    ProfScope prof(FAM_ATTN, s, 4.0 * N * H * S * S * dh);
     const size_t lds = (size_t)(2 * S * dhp + S * (dhp + 1) + S * (S + 1)) * sizeof(float);
+    NR_UNSUPPORTED(lds > MHSA_LDS_MAX, "mhsa: S=%d with head dim %d needs %zu B of LDS (> %zu)", S, dh, lds, MHSA_LDS_MAX);
+    ProfScope prof(FAM_ATTN, s, 4.0 * N * H * S * S * dh);
     const dim3 grid((unsigned)(N * H));
-#define NR_FWD(P)                                                                                                   \
+#define NR_FWD(P, T)                                                                                                \
     do {                                                                                                            \
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mhsa_fwd_kernel<P>),                               \
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mhsa_fwd_kernel<P, T>),                            \
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                            \
-        hipLaunchKernelGGL(mhsa_fwd_kernel<P>, grid, dim3(64), lds, s, qkv, mask, ctx, row_max, row_sum, S, H, dh, dc); \
+        hipLaunchKernelGGL((mhsa_fwd_kernel<P, T>), grid, dim3(T), lds, s, qkv, mask, ctx, row_max, row_sum, S, H, dh, dc); \
     } while (0)
-    if (dhp == 32) NR_FWD(32); else if (dhp == 64) NR_FWD(64); else NR_FWD(128);
+    if (S <= 64) { if (dhp == 32) NR_FWD(32, 64); else if (dhp == 64) NR_FWD(64, 64); else NR_FWD(128, 64); }
+    else         { if (dhp == 32) NR_FWD(32, 128); else if (dhp == 64) NR_FWD(64, 128); else NR_FWD(128, 128); }
 #undef NR_FWD
     return check_launch("mhsa_fwd");
 }
@@ -251,19 +254,21 @@ int mhsa_bwd(const float* qkv, const int64_t* mask, const float* ctx, const floa
         ProfScope prof(FAM_ATTN, s, 10.0 * N * H * S * S * dh);
         return mhsa_bwd_mfma(qkv, mask, dctx, row_max, row_sum, dqkv, N, S, H, dh, dc, s);
     }
-    NR_UNSUPPORTED(S > 64 || S < 1, "mhsa bwd: sequence length %d not in [1,64]", S);
+    NR_UNSUPPORTED(S > 128 || S < 1, "mhsa bwd: sequence length %d not in [1,128]", S);
     const int dhp = pick_dhp(dh);
     NR_UNSUPPORTED(dhp == 0 || dhp > 64, "mhsa bwd: head dim %d > 64", dh);
-    ProfScope prof(FAM_ATTN, s, 10.0 * N * H * S * S * dh);
     const size_t lds = (size_t)(2 * S * dhp + 3 * S * (dhp + 1) + 2 * S * (S + 1)) * sizeof(float);
+    NR_UNSUPPORTED(lds > MHSA_LDS_MAX, "mhsa bwd: S=%d with head dim %d needs %zu B of LDS (> %zu)", S, dh, lds, MHSA_LDS_MAX);
+    ProfScope prof(FAM_ATTN, s, 10.0 * N * H * S * S * dh);
     const dim3 grid((unsigned)(N * H));
-#define NR_BWD(P)                                                                                                   \
+#define NR_BWD(P, T)                                                                                                \
     do {                                                                                                            \
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mhsa_bwd_kernel<P>),                               \
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mhsa_bwd_kernel<P, T>),                            \
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                            \
-        hipLaunchKernelGGL(mhsa_bwd_kernel<P>, grid, dim3(64), lds, s, qkv, mask, ctx, dctx, row_max, row_sum, dqkv, S, H, dh, dc); \
+        hipLaunchKernelGGL((mhsa_bwd_kernel<P, T>), grid, dim3(T), lds, s, qkv, mask, ctx, dctx, row_max, row_sum, dqkv, S, H, dh, dc); \
     } while (0)
-    if (dhp == 32) NR_BWD(32); else NR_BWD(64);
+    if (S <= 64) { if (dhp == 32) NR_BWD(32, 64); else NR_BWD(64, 64); }
+    else         { if (dhp == 32) NR_BWD(32, 128); else NR_BWD(64, 128); }
 #undef NR_BWD
     return check_launch("mhsa_bwd");
 }

@@ -5,7 +5,7 @@
 //   * unmasked sum / mean over the history (Sum/Avg user encoders), fwd + bwd
 // A wave walks the sequence row by row; each row (D floats) is read once as 16-B vectors
 // (lane l holds columns 4*(l + 64*it)..+3), dot products are finished with wave reductions,
-// per-position scalars (scores, probabilities, logits) live one per lane (S, C <= 64).
+// per-position scalars (scores, probabilities, logits) live one per lane (C <= 64; pooling: SL = 1 or 2 per lane, S <= 128).
 #include "common.h"
 #include "seqops.h"
 
@@ -69,14 +69,14 @@ __device__ __forceinline__ void axpy_rows(float4 (&o)[IT], float a, const float4
 // accumulates prob * value over its own rows; the four partial rows are summed through LDS.
 constexpr int PB = 4;                  // rows in flight per wave
 
-template <int IT>
+template <int IT, int SL>
 __global__ __launch_bounds__(256) void pool_fwd_kernel(const float* __restrict__ key, const float* __restrict__ value,
                                                        const float* __restrict__ table, const int64_t* __restrict__ idx,
                                                        int64_t nrows,
                                                        const float* __restrict__ query, const int64_t* __restrict__ mask,
                                                        float* __restrict__ out, float* __restrict__ prob, int64_t nseq,
                                                        int S, int D) {
-    __shared__ float sc[64];
+    __shared__ float sc[64 * SL];
     __shared__ __attribute__((aligned(16))) float part[WPB][IT * 256];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int64_t n = blockIdx.x;
@@ -101,12 +101,16 @@ __global__ __launch_bounds__(256) void pool_fwd_kernel(const float* __restrict__
         }
     }
     __syncthreads();
+    // positions lane (and lane + 64 when SL == 2) of the softmax live in this lane
     const float myscore = lane < S ? sc[lane] : -INFINITY;
-    const float m = wave_max(myscore);
+    const float myscore2 = (SL == 2 && lane + 64 < S) ? sc[(SL - 1) * 64 + lane] : -INFINITY;
+    const float m = wave_max(SL == 2 ? fmaxf(myscore, myscore2) : myscore);
     const float e = lane < S ? expf(myscore - m) : 0.f;
-    const float sum = wave_sum(e);
-    const float p = e / sum;
+    const float e2 = (SL == 2 && lane + 64 < S) ? expf(myscore2 - m) : 0.f;
+    const float sum = wave_sum(SL == 2 ? e + e2 : e);
+    const float p = e / sum, p2 = e2 / sum;
     if (prob && w == 0 && lane < S) prob[n * S + lane] = p;
+    if (SL == 2 && prob && w == 0 && lane + 64 < S) prob[n * S + lane + 64] = p2;
     float4 acc[IT];
 #pragma unroll
     for (int it = 0; it < IT; ++it) acc[it] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -120,7 +124,7 @@ __global__ __launch_bounds__(256) void pool_fwd_kernel(const float* __restrict__
 #pragma unroll
         for (int b = 0; b < PB; ++b) {
             const int s = s0 + b * WPB;
-            if (s < S) axpy_rows<IT>(acc, __shfl(p, s, 64), v[b]);
+            if (s < S) axpy_rows<IT>(acc, __shfl((SL == 2 && s >= 64) ? p2 : p, s & 63, 64), v[b]);
         }
     }
     // fixed-order cross-wave sum (deterministic): wave w writes its partial, the block adds 0+1+2+3
@@ -145,13 +149,13 @@ __global__ __launch_bounds__(256) void pool_fwd_kernel(const float* __restrict__
 //   dq_part[n] = sum_s dscore_s key_s
 // key_is_value (AttnUserEncoder: key = value = x, no projection): dvalue_s += dkey_s, dkeypre unused.
 // Same block-per-sequence split as the forward kernel.
-template <int IT>
+template <int IT, int SL>
 __global__ __launch_bounds__(256) void pool_bwd_kernel(const float* __restrict__ key, const float* __restrict__ value,
                                                        const float* __restrict__ query, const float* __restrict__ prob,
                                                        const float* __restrict__ dout, float* __restrict__ dkeypre,
                                                        float* __restrict__ dvalue, float* __restrict__ dq_part,
                                                        int64_t nseq, int S, int D, int tanh_key, int key_is_value) {
-    __shared__ float sdp[64];
+    __shared__ float sdp[64 * SL];
     __shared__ __attribute__((aligned(16))) float part[WPB][IT * 256];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int64_t n = blockIdx.x;
@@ -160,6 +164,7 @@ __global__ __launch_bounds__(256) void pool_bwd_kernel(const float* __restrict__
     load_row<IT>(g, dout + n * (int64_t)D, D, lane);
     const float sq = sqrtf((float)D);
     const float p = lane < S ? prob[n * S + lane] : 0.f;
+    const float p2 = (SL == 2 && lane + 64 < S) ? prob[n * S + lane + 64] : 0.f;
     for (int s0 = w; s0 < S; s0 += WPB * PB) {
         float4 v[PB][IT];
 #pragma unroll
@@ -178,8 +183,9 @@ __global__ __launch_bounds__(256) void pool_bwd_kernel(const float* __restrict__
     }
     __syncthreads();
     const float mydp = lane < S ? sdp[lane] : 0.f;
-    const float tot = wave_sum(p * mydp);
-    const float dscore = p * (mydp - tot) / sq;
+    const float mydp2 = (SL == 2 && lane + 64 < S) ? sdp[(SL - 1) * 64 + lane] : 0.f;
+    const float tot = wave_sum(SL == 2 ? p * mydp + p2 * mydp2 : p * mydp);
+    const float dscore = p * (mydp - tot) / sq, dscore2 = p2 * (mydp2 - tot) / sq;
     float4 dq[IT];
 #pragma unroll
     for (int it = 0; it < IT; ++it) dq[it] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -194,8 +200,8 @@ __global__ __launch_bounds__(256) void pool_bwd_kernel(const float* __restrict__
         for (int b = 0; b < PB; ++b) {
             const int s = s0 + b * WPB;
             if (s >= S) continue;
-            const float ps = __shfl(p, s, 64);
-            const float dsc = __shfl(dscore, s, 64);
+            const float ps = __shfl((SL == 2 && s >= 64) ? p2 : p, s & 63, 64);
+            const float dsc = __shfl((SL == 2 && s >= 64) ? dscore2 : dscore, s & 63, 64);
             float4 dv[IT], dk[IT];
             axpy_rows<IT>(dq, dsc, k[b]);
 #pragma unroll
@@ -344,8 +350,23 @@ __global__ __launch_bounds__(256) void seq_broadcast_kernel(const float* __restr
         else                hipLaunchKernelGGL(KERNEL<8>, GRID, dim3(256), 0, s, __VA_ARGS__);      \
     } while (0)
 
-static int check_seq_dims(const char* what, int S, int D) {
-    NR_UNSUPPORTED(S < 1 || S > 64, "%s: %d positions per sequence not in [1,64]", what, S);
+#define NR_POOL_DISPATCH(KERNEL, GRID, ...)                                                         \
+    do {                                                                                            \
+        if (S <= 64) {                                                                              \
+            if (D <= 256)       hipLaunchKernelGGL((KERNEL<1, 1>), GRID, dim3(256), 0, s, __VA_ARGS__); \
+            else if (D <= 512)  hipLaunchKernelGGL((KERNEL<2, 1>), GRID, dim3(256), 0, s, __VA_ARGS__); \
+            else if (D <= 1024) hipLaunchKernelGGL((KERNEL<4, 1>), GRID, dim3(256), 0, s, __VA_ARGS__); \
+            else                hipLaunchKernelGGL((KERNEL<8, 1>), GRID, dim3(256), 0, s, __VA_ARGS__); \
+        } else {                                                                                    \
+            if (D <= 256)       hipLaunchKernelGGL((KERNEL<1, 2>), GRID, dim3(256), 0, s, __VA_ARGS__); \
+            else if (D <= 512)  hipLaunchKernelGGL((KERNEL<2, 2>), GRID, dim3(256), 0, s, __VA_ARGS__); \
+            else if (D <= 1024) hipLaunchKernelGGL((KERNEL<4, 2>), GRID, dim3(256), 0, s, __VA_ARGS__); \
+            else                hipLaunchKernelGGL((KERNEL<8, 2>), GRID, dim3(256), 0, s, __VA_ARGS__); \
+        }                                                                                           \
+    } while (0)
+
+static int check_seq_dims(const char* what, int S, int D, int smax = 64) {
+    NR_UNSUPPORTED(S < 1 || S > smax, "%s: %d positions per sequence not in [1,%d]", what, S, smax);
     NR_UNSUPPORTED(D % 4 != 0 || D > 2048 || D < 4, "%s: D=%d must be a multiple of 4 in [4,2048]", what, D);
     return NR_OK;
 }
@@ -353,20 +374,20 @@ static int check_seq_dims(const char* what, int S, int D) {
 int pool_fwd(const float* key, const float* value, const float* table, const int64_t* idx, int64_t nrows, const float* query,
              const int64_t* mask, float* out, float* prob, int64_t nseq, int S, int D, hipStream_t s) {
     if (nseq == 0) return NR_OK;
-    if (int rc = check_seq_dims("pooling", S, D)) return rc;
+    if (int rc = check_seq_dims("pooling", S, D, 128)) return rc;
     ProfScope prof(FAM_POOL, s, (double)nseq * (2.0 * S * D * 4 + D * 4));
     const dim3 grid((unsigned)nseq);
-    NR_SEQ_DISPATCH(pool_fwd_kernel, grid, key, value, table, idx, nrows, query, mask, out, prob, nseq, S, D);
+    NR_POOL_DISPATCH(pool_fwd_kernel, grid, key, value, table, idx, nrows, query, mask, out, prob, nseq, S, D);
     return check_launch("pool_fwd");
 }
 
 int pool_bwd(const float* key, const float* value, const float* query, const float* prob, const float* dout, float* dkeypre,
              float* dvalue, float* dq_part, int64_t nseq, int S, int D, int tanh_key, int key_is_value, hipStream_t s) {
     if (nseq == 0) return NR_OK;
-    if (int rc = check_seq_dims("pooling bwd", S, D)) return rc;
+    if (int rc = check_seq_dims("pooling bwd", S, D, 128)) return rc;
     ProfScope prof(FAM_POOL, s, (double)nseq * (4.0 * S * D * 4));
     const dim3 grid((unsigned)nseq);
-    NR_SEQ_DISPATCH(pool_bwd_kernel, grid, key, value, query, prob, dout, dkeypre, dvalue, dq_part, nseq, S, D, tanh_key, key_is_value);
+    NR_POOL_DISPATCH(pool_bwd_kernel, grid, key, value, query, prob, dout, dkeypre, dvalue, dq_part, nseq, S, D, tanh_key, key_is_value);
     return check_launch("pool_bwd");
 }
 

@@ -23,6 +23,15 @@ def write_synthetic_caches(manager, n_train_impr=64, n_dev_impr=24, vocab=None, 
             n = rng.randint(4, manager.max_title_length)
             titles.append([101] + [rng.randint(min(1000, V // 2), V - 1) for _ in range(n - 2)] + [102])
         save_pickle(titles, os.path.join(root, "news", "title_token_ids.pkl"))
+        abstracts = []
+        arng = random.Random(f"{seed}-{split}-abs")        # its own stream: the title / behaviour draws stay what they were
+        for i in range(n_news):
+            if i % 5 == 0:
+                abstracts.append([101, 102])               # no abstract
+                continue
+            n = arng.randint(4, manager.max_abs_length)
+            abstracts.append([101] + [arng.randint(min(1000, V // 2), V - 1) for _ in range(n - 2)] + [102])
+        save_pickle(abstracts, os.path.join(root, "news", "abs_token_ids.pkl"))
         save_pickle({f"N{i}": i for i in range(1, n_news + 1)}, os.path.join(root, "news", "nid2index.pkl"))
         n_impr = n_train_impr if split == "train" else n_dev_impr
         histories = [[rng.randint(1, n_news) for _ in range(rng.choice([0, 3, 17, 50, 70]))] for _ in range(n_impr)]

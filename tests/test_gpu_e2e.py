@@ -72,6 +72,22 @@ def test_main_twotower_nrms_pair_loss_decreases(tmp_path, monkeypatch):
     assert again == metrics
 
 
+def test_main_twotower_title_plus_abstract(tmp_path, monkeypatch):
+    """`-ef title abs` of the reference (scripts: sequence_length = 32 + 64 = 96 tokens): the attention and pooling
+    kernels run two waves per title; training, cached evaluation and metrics go through end to end."""
+    from utils.manager import Manager
+    from utils.synthetic import write_synthetic_caches
+    from main import twotower
+    monkeypatch.chdir(tmp_path)
+    m = Manager({"enable_fields": ["title", "abs"]}, command=f"-bs 8 -e 1 -ne tfm -ue attn -hd 48 -hn 4 -vs 4 -lr 1e-3 -s demo "
+                                                             f"--synthetic-plm -cr {tmp_path}/cache -dr {tmp_path}/data".split())
+    assert m.sequence_length == 96
+    m.news_nums = {"MINDdemo_train": 300, "MINDdemo_dev": 200}
+    write_synthetic_caches(m, n_train_impr=24, n_dev_impr=20, seed=3)
+    best = twotower.main(m.device, m)
+    assert 0.0 <= best["auc"] <= 1.0 and best["step"] > 0
+
+
 def test_device_side_batch_assembly_is_bit_exact(tmp_path, monkeypatch):
     """token rows gathered on the device from the resident [Nn,T] tables equal the rows the
     reference's __getitem__ ships (--host-assembly), and so does the loss."""

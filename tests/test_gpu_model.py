@@ -100,7 +100,7 @@ def _tfm_params_from_module(layer, prefix):
     return {prefix + k: v.detach().cpu().clone() for k, v in layer.state_dict().items()}
 
 
-@pytest.mark.parametrize("N,S,D,H", [(64, 32, 300, 12), (8, 50, 300, 12), (5, 9, 24, 4), (12, 32, 768, 12)])
+@pytest.mark.parametrize("N,S,D,H", [(64, 32, 300, 12), (8, 50, 300, 12), (5, 9, 24, 4), (12, 32, 768, 12), (6, 96, 300, 12)])
 def test_tfm_layer_train_mode_with_dropout(N, S, D, H):
     """training-mode layer (3 dropout sites) vs the oracle with the library's Philox keep-masks injected."""
     from models.modules.attention import TFMLayer
