@@ -251,9 +251,12 @@ __global__ __launch_bounds__(256) void score_fwd_kernel(const float* __restrict_
         float4 v[IT];
         load_row<IT>(v, row_ptr(cdd, table, idx, nrows, b, C, c, D), D, lane);
         const float x = dot_rows<IT>(v, u) / sq;
-        if (lane == c) mylogit = x;
+        if (lane == (c & 63)) mylogit = x;
+        if ((c & 63) == 63 || c == C - 1) {                  // flush 64 logits at a time: any C (the loss path needs C <= 64)
+            const int base = c & ~63;
+            if (base + lane <= c) logits[b * C + base + lane] = mylogit;
+        }
     }
-    if (lane < C) logits[b * C + lane] = mylogit;
     if (loss_b) {
         const float m = wave_max(mylogit);
         const float e = lane < C ? expf(mylogit - m) : 0.f;
@@ -394,7 +397,7 @@ int pool_bwd(const float* key, const float* value, const float* query, const flo
 int score_fwd(const float* cdd, const float* table, const int64_t* idx, int64_t nrows, const float* user, const int64_t* label, float* logits,
               float* loss_b, int64_t B, int C, int D, hipStream_t s) {
     if (B == 0) return NR_OK;
-    if (int rc = check_seq_dims("scoring", C, D)) return rc;
+    if (int rc = check_seq_dims("scoring", C, D, loss_b ? 64 : 65536)) return rc;       // plain logits: any C; fused CE: one logit per lane
     ProfScope prof(FAM_SCORE, s, (double)B * ((C + 1.0) * D * 4 + C * 4 + (idx ? C * 8 : 0)));
     const dim3 grid(cdiv(B, WPB));
     NR_SEQ_DISPATCH(score_fwd_kernel, grid, cdd, table, idx, nrows, user, label, logits, loss_b, B, C, D);

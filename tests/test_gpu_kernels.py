@@ -415,6 +415,9 @@ def test_eval_gather_dot(ops):
         assert relerr(user, ref_user) < FP32_TOL
         lg = ops.score_from_table(cg, cdd_idx.cuda(), user)
         assert relerr(lg, O.compute_logits(cache[cdd_idx], ref_user.unsqueeze(1))) < FP32_TOL
+    wide = torch.randint(0, Nn, (R, 150), generator=g)       # -is 150: more candidates per row than lanes
+    lg = ops.score_from_table(cg, wide.cuda(), user)
+    assert relerr(lg, O.compute_logits(cache[wide], ref_user.unsqueeze(1))) < FP32_TOL
     q = torch.randn(1, D, generator=g) * 0.1
     user = ops.pool_from_table(cg, his_idx.cuda(), q.cuda())
     assert relerr(user, O.attn_user_encoder({"userEncoder.user_query": q}, cache[his_idx]).squeeze(1)) < FP32_TOL
