@@ -100,7 +100,8 @@ def _tfm_params_from_module(layer, prefix):
     return {prefix + k: v.detach().cpu().clone() for k, v in layer.state_dict().items()}
 
 
-@pytest.mark.parametrize("N,S,D,H", [(64, 32, 300, 12), (8, 50, 300, 12), (5, 9, 24, 4), (12, 32, 768, 12), (6, 96, 300, 12)])
+@pytest.mark.parametrize("N,S,D,H", [(64, 32, 300, 12), (8, 50, 300, 12), (5, 9, 24, 4), (12, 32, 768, 12), (6, 96, 300, 12),
+                                     (1760, 32, 300, 12)])     # the news tower of BASELINE configs[1] at B = 32, whole
 def test_tfm_layer_train_mode_with_dropout(N, S, D, H):
     """training-mode layer (3 dropout sites) vs the oracle with the library's Philox keep-masks injected."""
     from models.modules.attention import TFMLayer
@@ -213,6 +214,49 @@ def test_bert_bf16_build_vs_oracle():
     loss32 = model(X)
     assert abs(loss32.item() - loss_ref.item()) < FP32_TOL * abs(loss_ref.item())
     assert loss32.item() != loss.item()
+
+
+def test_full_size_step_properties():
+    """BASELINE configs[1] at its full per-GPU size (B = 32: 56 320 token rows, V = 30 522): what must hold whatever
+    the size — the step is reproducible (fixed split-K / reduction orders: every gradient but the atomically
+    scattered token table is bit-identical between two runs), the dense products are linear, pooling probabilities
+    sum to one, and the loss is the mean of per-impression cross-entropies >= 0."""
+    from newsrec_hip import ops
+    meta = dict(V=30522, E=300, D=300, H=12, T=32, L=50, K=4, B=32, Nn=20000)
+    model, mgr = build_model(meta, "tfm", "tfm")
+    g = torch.Generator().manual_seed(77)
+    ids, msk = synth_news_table(g, meta["Nn"], meta["T"], meta["V"])
+    X = synth_batch(g, meta["B"], meta["K"] + 1, meta["L"], meta["Nn"], ids, msk)
+    model = model.cuda().train()
+    runs = []
+    for _ in range(2):
+        model.zero_grad(set_to_none=True)
+        torch.manual_seed(5)
+        ops.dropout_stream.reset(0)            # same (seed, site) pairs -> same Philox keep-masks on both runs
+        loss = model(X)
+        loss.backward()
+        runs.append((loss.detach().clone(), {n: p_.grad.detach().clone() for n, p_ in model.named_parameters()}))
+    (l0, g0), (l1, g1) = runs
+    assert torch.isfinite(l0) and l0.item() > 0
+    assert torch.equal(l0, l1)
+    for n in g0:
+        if "embedding" in n:                   # float atomics: order-dependent in the last bits
+            assert relerr(g1[n], g0[n]) < 1e-6, n
+        else:
+            assert torch.equal(g0[n], g1[n]), n
+    # linearity of the dense product at R = 56 320
+    R, K, N = 56320, 300, 900
+    x1, x2 = torch.randn(R, K, generator=g).cuda(), torch.randn(R, K, generator=g).cuda()
+    w = (torch.randn(N, K, generator=g) / K ** 0.5).cuda()
+    lhs = ops.linear_fwd(2.5 * x1 + x2, w, None, "none", None)
+    rhs = 2.5 * ops.linear_fwd(x1, w, None, "none", None) + ops.linear_fwd(x2, w, None, "none", None)
+    assert relerr(lhs, rhs) < FP32_TOL
+    # dW of a sum of upstream gradients = sum of dWs (split-K path, K = 56 320)
+    dy1, dy2 = torch.randn(R, N, generator=g).cuda(), torch.randn(R, N, generator=g).cuda()
+    dwa, dba = ops.linear_bwd_weight(dy1 + dy2, x1)
+    dw1, db1 = ops.linear_bwd_weight(dy1, x1)
+    dw2, db2 = ops.linear_bwd_weight(dy2, x1)
+    assert relerr(dwa, dw1 + dw2) < FP32_TOL and relerr(dba, db1 + db2) < FP32_TOL
 
 
 def test_cpu_tensors_fail_loudly():
