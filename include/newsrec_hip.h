@@ -49,7 +49,7 @@ int nr_prof_read(int family, double* ms, int64_t* launches, double* work);
 
 /* ---- matrix-core precision of the GEMM family -------------------------------------------
  * mode 0 (default): exact fp32 MFMA (the 1e-5 parity bar).  mode 1: operands rounded to bf16 on their way into
- * LDS, f32 accumulate (v_mfma_f32_32x32x16_bf16) for every non-conv product with M, N, K >= 128; tensors in HBM
+ * LDS, f32 accumulate (v_mfma_f32_32x32x16_bf16) for every product with M, N, K >= 128 (conv views included); tensors in HBM
  * stay fp32.  This is the "bf16-MFMA build" of SURVEY §8 a7 (AllBertNewsEncoder, encoder.py:62-77; parity bar
  * 1e-2); the closest thing in the reference is running the model under torch.autocast.  Process-wide and sticky:
  * set it before the first step.  nr_set_gemm_compute returns NR_ERR_ARG for an unknown mode. */

@@ -596,25 +596,34 @@ __device__ __forceinline__ f32x4 ldg4(const void* p) { return *reinterpret_cast<
 // k-contiguous 128 x 32 tile: thread loads f32x4 (row = t/8 + 32*i, k = (t%8)*4), zero past the row / k range
 struct LoaderKCH {
     const float* ptr[4];
-    unsigned valid;
+    unsigned valid, first, last;   // per pass i, bit i: row in range / conv t == 0 / conv t == T-1
     int c4;
     const float* safe;
-    __device__ __forceinline__ void init(const float* base, int64_t ld, int row0, int nrows, int tid, const float* safe_) {
+    __device__ __forceinline__ void init(const float* base, int64_t ld, int row0, int nrows, int tid, int convT, const float* safe_) {
         c4 = (tid & 7) * 4;
         safe = safe_;
-        valid = 0;
+        valid = first = last = 0;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int r = row0 + (tid >> 3) + 32 * i;
             const bool ok = r < nrows;
             ptr[i] = base + (int64_t)(ok ? r : row0) * ld + c4;
             if (ok) valid |= 1u << i;
+            if (convT > 0) {
+                const int t = r % convT;
+                if (t == 0) first |= 1u << i;
+                if (t == convT - 1) last |= 1u << i;
+            }
         }
     }
-    __device__ __forceinline__ void load(f32x4& r0, f32x4& r1, f32x4& r2, f32x4& r3, int k0, int K) const {
-        const bool kok = k0 + c4 < K;
+    // convE > 0: the row is an im2col view of 3 token rows; its first / last convE floats are zero at the title borders
+    __device__ __forceinline__ void load(f32x4& r0, f32x4& r1, f32x4& r2, f32x4& r3, int k0, int K, int convE) const {
+        const int k = k0 + c4;
+        const bool kok = k < K;
+        const unsigned dead = (k < convE ? first : 0u) | ((convE > 0 && k >= 2 * convE) ? last : 0u);
+        const unsigned live = kok ? (valid & ~dead) : 0u;
         const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-        const bool o0 = kok && (valid & 1u), o1 = kok && (valid & 2u), o2 = kok && (valid & 4u), o3 = kok && (valid & 8u);
+        const bool o0 = live & 1u, o1 = live & 2u, o2 = live & 4u, o3 = live & 8u;
         const f32x4 v0 = ldg4(o0 ? ptr[0] + k0 : safe), v1 = ldg4(o1 ? ptr[1] + k0 : safe);
         const f32x4 v2 = ldg4(o2 ? ptr[2] + k0 : safe), v3 = ldg4(o3 ? ptr[3] + k0 : safe);
         r0 = o0 ? v0 : z; r1 = o1 ? v1 : z; r2 = o2 ? v2 : z; r3 = o3 ? v3 : z;
@@ -646,25 +655,32 @@ struct LoaderRMH {
     int64_t ld;
     uint32_t off;
     bool cvalid;
-    int c;
+    int c, col;
     const float* safe;
     __device__ __forceinline__ void init(const float* base_, int64_t ld_, int col0, int ncols, int tid, const float* safe_) {
         base = base_; ld = ld_; safe = safe_;
         const int w = tid >> 6, lane = tid & 63, a = lane & 7;
         c = lane >> 3;
-        const int col = col0 + 32 * w + 4 * a;
+        col = col0 + 32 * w + 4 * a;
         cvalid = col < ncols;
         off = (uint32_t)(2 * c * (int)ld + (cvalid ? col : col0)) * 4u;
     }
-    // r0/r1: rows k, k+1 of the k pair c; r2/r3: of the k pair 8 + c
-    __device__ __forceinline__ void load(f32x4& r0, f32x4& r1, f32x4& r2, f32x4& r3, int k0, int K) const {
+    // r0/r1: rows k, k+1 of the k pair c; r2/r3: of the k pair 8 + c.  convT > 0: the operand is the im2col view,
+    // k = token row: columns < convE are zero at t == 0, columns >= 2*convE at t == T-1
+    __device__ __forceinline__ bool conv_dead(int k, int convT, int convE) const {
+        if (convT <= 0) return false;
+        const int t = k % convT;
+        return (t == 0 && col < convE) || (t == convT - 1 && col >= 2 * convE);
+    }
+    __device__ __forceinline__ void load(f32x4& r0, f32x4& r1, f32x4& r2, f32x4& r3, int k0, int K, int convT, int convE) const {
         const uint32_t rowb = (uint32_t)ld * 4u;
         const f32x4 z = {0.f, 0.f, 0.f, 0.f};
         const char* kb0 = reinterpret_cast<const char*>(base + (int64_t)k0 * ld);             // uniform
         const char* kb1 = reinterpret_cast<const char*>(base + (int64_t)(k0 + 16) * ld);
         const char* sf = reinterpret_cast<const char*>(safe);
         const int k = k0 + 2 * c;
-        const bool o0 = cvalid && k < K, o1 = cvalid && k + 1 < K, o2 = cvalid && k + 16 < K, o3 = cvalid && k + 17 < K;
+        const bool o0 = cvalid && k < K && !conv_dead(k, convT, convE), o1 = cvalid && k + 1 < K && !conv_dead(k + 1, convT, convE);
+        const bool o2 = cvalid && k + 16 < K && !conv_dead(k + 16, convT, convE), o3 = cvalid && k + 17 < K && !conv_dead(k + 17, convT, convE);
         const f32x4 v0 = ldg4(o0 ? kb0 + off : sf), v1 = ldg4(o1 ? kb0 + off + rowb : sf);
         const f32x4 v2 = ldg4(o2 ? kb1 + off : sf), v3 = ldg4(o3 ? kb1 + off + rowb : sf);
         r0 = o0 ? v0 : z; r1 = o1 ? v1 : z; r2 = o2 ? v2 : z; r3 = o3 ? v3 : z;
@@ -724,8 +740,13 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const GemmParams p) {
 
     f32x4 a0, a1, a2, a3, b0, b1, b2, b3;                 // the next k-tile on its way HBM -> LDS
     LoaderKCH lkA, lkB; LoaderRMH lrA, lrB;
-    if (A_KC) lkA.init(p.A, p.lda, m0, p.M, tid, p.A); else lrA.init(p.A, p.lda, m0, p.M, tid, p.A);
-    if (B_KC) lkB.init(p.B, p.ldb, n0, p.N, tid, p.B); else lrB.init(p.B, p.ldb, n0, p.N, tid, p.B);
+    // conv views (gemm.hip header): they start one token row (conv_E floats) before the tensor
+    const int convA = (A_KC && p.conv_on == 1) ? p.conv_T : 0;
+    const int convB = (!B_KC && p.conv_on == 2) ? p.conv_T : 0;
+    const float* safeA = p.A + (convA ? p.conv_E : 0);
+    const float* safeB = p.B + (convB ? p.conv_E : 0);
+    if (A_KC) lkA.init(p.A, p.lda, m0, p.M, tid, convA, safeA); else lrA.init(p.A, p.lda, m0, p.M, tid, safeA);
+    if (B_KC) lkB.init(p.B, p.ldb, n0, p.N, tid, 0, safeB);     else lrB.init(p.B, p.ldb, n0, p.N, tid, safeB);
 
     // bias gradient riding on dW (A reduction-major): exact fp32 column sums of the A tile taken from the
     // staging registers before they are rounded; the 16 lanes that share a column meet in the epilogue
@@ -734,8 +755,8 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const GemmParams p) {
 
     auto gload = [&](int kt) {
         const int k0 = kt * BK;
-        if (A_KC) lkA.load(a0, a1, a2, a3, k0, p.K); else lrA.load(a0, a1, a2, a3, k0, p.K);
-        if (B_KC) lkB.load(b0, b1, b2, b3, k0, p.K); else lrB.load(b0, b1, b2, b3, k0, p.K);
+        if (A_KC) lkA.load(a0, a1, a2, a3, k0, p.K, convA ? p.conv_E : 0); else lrA.load(a0, a1, a2, a3, k0, p.K, 0, 0);
+        if (B_KC) lkB.load(b0, b1, b2, b3, k0, p.K, 0);                    else lrB.load(b0, b1, b2, b3, k0, p.K, convB, p.conv_E);
     };
     auto lstore = [&](int buf) {
         uint32_t* As = smem + buf * STAGE;
@@ -942,8 +963,8 @@ int gemm_f32(GemmParams p, bool a_kc, bool b_kc, float* workspace, size_t ws_byt
     }
     int rc;
     // bf16-input matrix cores when the caller asked for them (nr_set_gemm_compute(1)) and the product is big enough
-    // to matter; conv views and small products stay on the exact fp32 kernel
-    const bool half = g_gemm_compute.load() == 1 && !p.conv_on && p.M >= 128 && p.N >= 128 && p.K >= 128;
+    // to matter; small products stay on the exact fp32 kernel
+    const bool half = g_gemm_compute.load() == 1 && p.M >= 128 && p.N >= 128 && p.K >= 128;
     if (half) {
         if (a_kc && b_kc)        rc = launch_bf16<true, true>(q, s);
         else if (a_kc && !b_kc)  rc = launch_bf16<true, false>(q, s);

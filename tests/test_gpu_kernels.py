@@ -143,7 +143,34 @@ def test_bf16_gemm_forward_backward(bf16_gemm, R, K, N):
     assert relerr(db, dy.sum(0)) < FP32_TOL                     # the bias gradient is summed from the fp32 tile
 
 
-def test_bf16_mode_leaves_small_and_conv_products_exact(bf16_gemm):
+@pytest.mark.parametrize("M,T,E,D", [(440, 32, 768, 768), (55, 32, 300, 300), (9, 20, 132, 140)])
+def test_bf16_conv1d_relu(bf16_gemm, M, T, E, D):
+    """the CNN news encoder's implicit-GEMM conv in the bf16 build: forward, input gradient and weight gradient equal
+    the convolution of the bf16-rounded operands (f32 accumulate) to the fp32 bar, and the fp32 convolution to 1e-2;
+    the title borders (zero padding of the im2col view) are exercised by every title."""
+    ops = bf16_gemm
+    g = G(33)
+    x = torch.randn(M, T, E, generator=g)
+    w = torch.randn(D, E, 3, generator=g) / math.sqrt(3 * E)
+    b = 0.1 * torch.randn(D, generator=g)
+    dy = torch.randn(M, T, D, generator=g)
+    xr, wr, br = _rb(x).requires_grad_(True), _rb(w).requires_grad_(True), b.clone().requires_grad_(True)
+    pre = F.conv1d(xr.transpose(1, 2), wr, br, padding=1).transpose(1, 2)
+    ref = F.relu(pre)
+    xg, wg, bg = x.cuda().requires_grad_(True), w.cuda().requires_grad_(True), b.cuda().requires_grad_(True)
+    y = ops.conv1d_k3_relu(xg, wg, bg)
+    assert relerr(y, ref) < FP32_TOL
+    assert relerr(y, F.relu(F.conv1d(x.transpose(1, 2), w, b, padding=1).transpose(1, 2))) < 1e-2
+    # same ReLU mask on both sides (a pre-activation within rounding of 0 may flip): feed the masked gradient
+    gm = dy * (y.detach().cpu() > 0)
+    pre.backward(_rb(gm))                                    # the kernel rounds the upstream gradient too
+    y.backward(dy.cuda())
+    assert relerr(xg.grad, xr.grad) < 2e-5
+    assert relerr(wg.grad, wr.grad) < 2e-5
+    assert relerr(bg.grad, gm.sum((0, 1))) < 2e-5           # bias gradient: exact fp32 column sums
+
+
+def test_bf16_mode_leaves_small_products_exact(bf16_gemm):
     ops = bf16_gemm
     g = G(32)
     x = torch.randn(96, 64, generator=g)
