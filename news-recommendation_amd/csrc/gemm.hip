@@ -977,7 +977,8 @@ int gemm_f32(GemmParams p, bool a_kc, bool b_kc, float* workspace, size_t ws_byt
     // ten k-tiles per workgroup are mostly prologue/epilogue, which 7 resident waves per SIMD overlap better
     const bool small = (int64_t)cdiv(p.M, 128) * cdiv(p.N, 64) * p.ksplit < 192 || (p.N <= 320 && p.K <= 512);
     if (a_kc && b_kc)        rc = small ? launch_tiled<true, true, 1, 1>(q, s) : wide ? launch_tiled<true, true, 2, 2>(q, s) : launch_tiled<true, true, 2, 1>(q, s);
-    else if (a_kc && !b_kc)  rc = small ? launch_tiled<true, false, 1, 1>(q, s) : wide ? launch_tiled<true, false, 2, 2>(q, s) : launch_tiled<true, false, 2, 1>(q, s);
+    // dX (B reduction-major): 128x64 at 4 workgroups/CU also wins on N % 128 == 0 (768-d: 124-128 vs 117-123 TF/s)
+    else if (a_kc && !b_kc)  rc = small ? launch_tiled<true, false, 1, 1>(q, s) : launch_tiled<true, false, 2, 1>(q, s);
     else if (!a_kc && !b_kc) {
         if (!p.conv_on && !wide && (p.epi == EPI_NONE || p.ksplit > 1) && tall_tile(p.M, p.N, p.K)) rc = launch_tiled<false, false, 5, 1>(q, s);
         else if (!wide && short_tile(p.M)) rc = launch_tiled<false, false, 1, 1>(q, s);
