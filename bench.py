@@ -212,11 +212,25 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the product has no CPU path")
+    # rehearsal on a one-GPU box only (never set by the driver): every rank on device 0, gloo instead of RCCL, so the
+    # multi-rank logic (DDP wrap, sharded cache + all-reduce, max-over-ranks timing) can be exercised without 2 GPUs
+    rehearse = os.environ.get("NR_BENCH_REHEARSE_ONE_GPU") == "1"
+    if os.environ.get("NR_BENCH_HANG_DUMP"):    # debugging aid: python stacks of every rank after N seconds
+        import faulthandler
+        os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+        faulthandler.dump_traceback_later(int(os.environ["NR_BENCH_HANG_DUMP"]), exit=True,
+                                          file=open(os.path.join(ROOT, "gpurun_out", f"hang_rank{rank}.txt"), "w"))
+    if rehearse:
+        local = 0
     torch.cuda.set_device(local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        if rehearse:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
     from newsrec_hip import ops
+    from utils.dp import all_reduce_
     ops.set_gemm_compute(args.gemm)
 
     B = args.batch_size
@@ -227,8 +241,8 @@ def main():
     model = model.cuda().train()
     net = model
     if world > 1:
-        net = torch.nn.parallel.DistributedDataParallel(model, device_ids=[local], output_device=local,
-                                                        gradient_as_bucket_view=True)
+        from utils.dp import FlatGradSync
+        net = FlatGradSync(model, world)
     opt, _ = model.get_optimizer(mgr, 1000)
 
     g = torch.Generator().manual_seed(1000 + rank)
@@ -239,16 +253,22 @@ def main():
         batches.append({k: v.cuda() for k, v in X.items()})
 
     def step(i):
-        opt.zero_grad(set_to_none=True)
+        if world > 1:
+            net.zero_grad()
+        else:
+            opt.zero_grad(set_to_none=True)
         loss = net(batches[i % len(batches)])
         loss.backward()
+        if world > 1:
+            net.sync()                       # one all-reduce (average) over the flat gradient buffer
         opt.step()
         return loss
 
     def fence():
+        torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
-        torch.cuda.synchronize()
+            torch.cuda.synchronize()
 
     for i in range(args.warmup):
         step(i)
@@ -260,7 +280,7 @@ def main():
     dt = time.perf_counter() - t0
     if world > 1:
         tt = torch.tensor([dt], device="cuda", dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        all_reduce_(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
     final_loss = float(loss)
     ms_per_step = 1000.0 * dt / args.steps
@@ -333,7 +353,7 @@ def main():
                 cache = torch.zeros(NEWS_DEV, D, device="cuda")
                 cache[lo:hi] = part
                 if world > 1:
-                    dist.all_reduce(cache)
+                    all_reduce_(cache)
                 model.news_embeddings = cache
                 Re, Ce = 200, 20
                 rows = []
@@ -382,7 +402,7 @@ def main():
                 t_full = time.perf_counter() - t0
             if world > 1:
                 tt = torch.tensor([t_enc, t_inf, t_full], device="cuda", dtype=torch.float64)
-                dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+                all_reduce_(tt, op=dist.ReduceOp.MAX)
                 t_enc, t_inf, t_full = [float(v) for v in tt.tolist()]
             out["eval"] = {"news_cache_rows": NEWS_DEV, "cache_build_news_per_s": round(NEWS_DEV / t_enc, 1),
                            "infer_rows_per_s_batch200": round(world * n_it * Re / t_inf, 1),

@@ -1,10 +1,10 @@
 """python -m main.twotower [flags] — train / evaluate a two-tower recommender on MI355X.
 
 Same entry, flags and encoder selection as the reference's main/twotower.py:8-63: one process per
-GPU (mp.spawn), DistributedDataParallel over the "nccl" backend (RCCL over xGMI on ROCm).
+GPU (mp.spawn), data-parallel gradient averaging over the "nccl" backend (RCCL over xGMI on ROCm; utils/dp.py).
 """
 import torch.multiprocessing as mp
-from torch.nn.parallel import DistributedDataParallel as DDP
+from utils.dp import FlatGradSync
 
 from utils.manager import Manager
 from models.TwoTower import TwoTowerModel
@@ -27,10 +27,8 @@ def main(rank, manager):
         model.attach_news_tokens(ds.token_ids, ds.attn_masks)
     if manager.mode == "train":
         if manager.world_size > 1:
-            # gradient buckets are views of the flat all-reduce buffers: the dense V x E table gradient
-            # (the bulk of the bytes) is reduced in place, overlapped with the rest of the backward
-            kw = dict(device_ids=[manager.device], output_device=manager.device) if manager.device != "cpu" else {}
-            model = DDP(model, gradient_as_bucket_view=True, **kw)
+            # every gradient is a view of one flat buffer that is all-reduced (averaged) once per step
+            model = FlatGradSync(model, manager.world_size)
         return manager.train(model, loaders)
     if manager.mode == "dev":
         manager.load(model)

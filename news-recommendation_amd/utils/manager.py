@@ -200,7 +200,8 @@ class Manager():
     # ------------------------------------------------------------------ checkpoints / log
     @staticmethod
     def _unwrap(model):
-        return model.module if isinstance(model, torch.nn.parallel.DistributedDataParallel) else model
+        from utils.dp import FlatGradSync
+        return model.module if isinstance(model, (torch.nn.parallel.DistributedDataParallel, FlatGradSync)) else model
 
     def _ckpt_path(self, model, tag):
         return f"data/ckpts/{model.name}/{self.scale}/{tag}.model"
@@ -264,9 +265,14 @@ class Manager():
             epoch_loss = None
             bar = tqdm(loader, ncols=120, disable=self.rank != 0)
             for step, x in enumerate(bar, 1):
-                optimizer.zero_grad(set_to_none=True)
+                if hasattr(model, "sync"):                 # FlatGradSync: gradients live in one flat buffer
+                    model.zero_grad()
+                else:
+                    optimizer.zero_grad(set_to_none=True)
                 loss = model(x)
                 loss.backward()
+                if hasattr(model, "sync"):
+                    model.sync()
                 optimizer.step()
                 if scheduler:
                     scheduler.step()

@@ -101,3 +101,51 @@ def test_sharded_eval_world2_equals_single_process():
     assert np.array_equal(c0, cache1) and np.array_equal(c1, cache1)   # every rank holds the whole cache
     n = len(loaders["dev"].dataset)
     assert s0 == (0, round(n / 2)) and s1 == (round(n / 2), n)  # contiguous impression shards
+
+
+def _grad_sync_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from utils.dp import FlatGradSync
+    torch.manual_seed(100 + rank)                       # replicas start DIFFERENT: the wrapper must broadcast rank 0's weights
+    net = torch.nn.Sequential(torch.nn.Embedding(50, 8), torch.nn.Linear(8, 8), torch.nn.Tanh(), torch.nn.Linear(8, 1))
+    dp = FlatGradSync(net, world)
+    opt = torch.optim.Adam(net.parameters(), lr=1e-2)
+    g = torch.Generator().manual_seed(7)
+    ids = torch.randint(0, 50, (8, 5), generator=g)     # the full batch; rank r takes rows r::world
+    full = torch.nn.Sequential(torch.nn.Embedding(50, 8), torch.nn.Linear(8, 8), torch.nn.Tanh(), torch.nn.Linear(8, 1))
+    full.load_state_dict(net.state_dict())
+    full_opt = torch.optim.Adam(full.parameters(), lr=1e-2)
+    for _ in range(3):
+        dp.zero_grad()
+        dp(ids[rank::world]).square().mean().backward()
+        dp.sync()
+        opt.step()
+        full_opt.zero_grad()
+        full(ids).square().mean().backward()            # mean over the whole batch = mean of the per-rank means
+        full_opt.step()
+    flat = torch.cat([p.detach().reshape(-1) for p in net.parameters()])
+    ref = torch.cat([p.detach().reshape(-1) for p in full.parameters()])
+    both = [torch.empty_like(flat) for _ in range(world)]
+    dist.all_gather(both, flat)
+    q.put((rank, bool(torch.equal(both[0], both[1])), float((flat - ref).abs().max()), all(p.grad is v for p, v in zip(dp.params, dp.views))))
+    dist.destroy_process_group()
+
+
+def test_flat_grad_sync_two_ranks():
+    """utils/dp.py (what replaces DistributedDataParallel): rank 0's weights are broadcast, every .grad stays a view of
+    the flat buffer, one all-reduce per step averages it, and three Adam steps on two half batches equal three steps
+    on the whole batch on one replica."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_grad_sync_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(60)
+    for rank, same, err, views in res:
+        assert same, "replicas diverged"
+        assert err < 1e-6, err
+        assert views
