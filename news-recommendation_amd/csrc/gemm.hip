@@ -907,7 +907,7 @@ size_t gemm_workspace_bytes(int M, int N, int ksplit) {
 }
 
 int choose_ksplit(int M, int N, int K) {
-    // dW GEMMs: tiny MxN, huge K.  Two pulls (swept on MI355X, tools/dw_lab.sh): enough workgroups to fill the
+    // dW GEMMs: tiny MxN, huge K.  Two pulls (swept on MI355X): enough workgroups to fill the
     // chip (>= 512), and slices of ~32 k-tiles — shorter slices than the fill needs only add slab traffic, longer
     // ones leave the single-buffered loop latency-bound (dW[1200,300]: 68 TF/s at 512 workgroups, 85 at 2048+)
     const int tiles = cdiv(M, dw_tile_rows(M, N, K)) * cdiv(N, 64);
