@@ -553,7 +553,7 @@ size_t nr_gru_fwd_ws_bytes(int64_t B, int64_t H) { return skinny_ws_bytes(B, 3 *
 
 size_t nr_gru_bwd_ws_bytes(int64_t B, int64_t L, int64_t Din, int64_t H) {
     return 2 * pad256((size_t)B * L * 3 * H) + 3 * pad256((size_t)B * H) +
-           std::max(std::max(bwd_weight_ws(B * L, 3 * H, H, true), bwd_weight_ws(B * L, 3 * H, Din, true)), skinny_ws_bytes(B, H, 3 * H)) + 1024;
+           std::max(std::max(bwd_weight_ws(B * L, 3 * H, H, true), bwd_weight_ws(B * L, 3 * H, Din, true)), skinny_ws_bytes(B, H, 3 * H)) + 2048;
 }
 
 int nr_gru_bwd_f32(const float* dh_out, const float* x, const float* w_ih, const float* w_hh, int64_t B, int64_t L, int64_t Din,
@@ -568,10 +568,20 @@ int nr_gru_bwd_f32(const float* dh_out, const float* x, const float* w_ih, const
     float* dgh = bump(cur, (size_t)B * L * 3 * H);           // rows t*B + b  (the order of hall)
     float* direct = bump(cur, (size_t)B * H);                 // dh_t * z
     float* pp[2] = {bump(cur, (size_t)B * H), bump(cur, (size_t)B * H)};
+    unsigned* counter = reinterpret_cast<unsigned*>(bump(cur, 64));
     const size_t rest = ws_bytes - (size_t)(cur - (char*)ws);
     const float* dh = dh_out;
     int k = 0;
-    for (int t = (int)L - 1; t >= 0; --t) {
+    // the recurrence: one persistent launch when the shape allows it, else a gate kernel + a skinny GEMM per step
+    bool stepwise = true;
+    if (gru_seq_bwd_supported((int)B, (int)H) && !g_gru_per_step) {
+        const int rc = gru_seq_bwd(dh_out, gates, hall, lens, w_hh, dgi, dgh, (int)B, (int)L, (int)H, counter, s);
+        if (rc != NR_ERR_UNSUPPORTED) {
+            if (rc != NR_OK) return rc;
+            stepwise = false;
+        }
+    }
+    for (int t = (int)L - 1; t >= 0 && stepwise; --t) {
         float* dgh_t = dgh + (size_t)t * B * 3 * H;
         if (int rc = gru_gate_bwd(dh, gates + (size_t)t * B * 4 * H, hall + (size_t)t * B * H, lens, dgi, dgh_t, direct, (int)B,
                                   (int)L, (int)H, t, s)) return rc;

@@ -230,6 +230,130 @@ int gru_seq_fwd(const float* gi, const float* w_hh, const float* b_hh, const int
     return check_launch("gru_seq_fwd");
 }
 
+// ---- the backward recurrence in one persistent launch: same scheme, transposed roles.  Workgroup w owns 32 hidden
+// units (one MFMA tile of dh columns); its [3H, 32] slice of W_hh stays in registers, split over 12 waves by k.
+// Per step: gate backward for the owned units (dh_t is local) -> publish dGH_t[:, owned r|z|n columns] and write
+// dGI_t -> grid barrier -> every wave multiplies its k-slice of the full dGH_t into a 32x32 partial -> LDS ->
+// dh_{t-1} = dh_t * z + dGH_t W_hh for the owned units.  Each step publishes into its own slab of dgh [L, B, 3H]
+// (kept anyway for dW_hh), so one barrier per step is enough.
+constexpr int GRU_NSB = 48;          // MFMAs per wave and batch tile at most: k-slice <= 96, 3H <= 1152
+
+__global__ __launch_bounds__(64 * GRU_WAVES) void gru_seq_bwd_kernel(const float* __restrict__ dh_out, const float* __restrict__ gates,
+                                                                    const float* __restrict__ hall, const int* __restrict__ lens,
+                                                                    const float* __restrict__ w_hh, float* __restrict__ dgi,
+                                                                    float* dgh, int B, int L, int H, int KS, unsigned* counter) {
+    extern __shared__ float gsm[];
+    float* part = gsm;                                   // [12][32 * 33]
+    float* dhs = gsm + GRU_WAVES * 32 * GRU_PLD;         // [ceil(B/32)*32][33]: dh_t, then dh_t * z, then dh_{t-1}
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int q = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, hh = lane >> 5;
+    const int j0 = blockIdx.x * 32;
+    const int K3 = 3 * H;
+    const int kq0 = q * KS, nu = KS / 8;
+    const int btiles = (B + 31) / 32;
+
+    float w[GRU_NSB];
+    {
+        const int j = j0 + l31;
+#pragma unroll
+        for (int u = 0; u < GRU_NSB / 4; ++u) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int k = kq0 + 8 * u + 4 * hh + i;
+                w[4 * u + i] = (u < nu && k < K3 && j < H) ? w_hh[(int64_t)k * H + j] : 0.f;
+            }
+        }
+    }
+    for (int e = tid; e < btiles * 32 * 32; e += 64 * GRU_WAVES) {
+        const int b = e >> 5, n = e & 31, j = j0 + n;
+        dhs[b * GRU_PLD + n] = (b < B && j < H) ? dh_out[(int64_t)b * H + j] : 0.f;
+    }
+    __syncthreads();
+
+    for (int t = L - 1; t >= 0; --t) {
+        float* dgh_t = dgh + (size_t)t * B * K3;
+        // gate backward for the owned units
+        for (int e = tid; e < btiles * 32 * 32; e += 64 * GRU_WAVES) {
+            const int b = e >> 5, n = e & 31, j = j0 + n;
+            if (b >= B || j >= H) continue;
+            const float g = dhs[b * GRU_PLD + n];
+            float* gib = dgi + ((int64_t)b * L + t) * K3;
+            float* ghb = dgh_t + (int64_t)b * K3;
+            if (t >= lens[b]) {
+                gib[j] = 0.f; gib[H + j] = 0.f; gib[2 * H + j] = 0.f;
+                st_agent(ghb + j, 0.f); st_agent(ghb + H + j, 0.f); st_agent(ghb + 2 * H + j, 0.f);
+                continue;                                 // dh passes through a frozen step unchanged
+            }
+            const float* sv = gates + ((size_t)t * B + b) * 4 * H;
+            const float r = sv[j], z = sv[H + j], nn = sv[2 * H + j], ghn = sv[3 * H + j];
+            const float hp = hall[((size_t)t * B + b) * H + j];
+            const float dn_pre = g * (1.0f - z) * (1.0f - nn * nn);
+            const float dz_pre = g * (hp - nn) * z * (1.0f - z);
+            const float dr_pre = dn_pre * ghn * r * (1.0f - r);
+            gib[j] = dr_pre; gib[H + j] = dz_pre; gib[2 * H + j] = dn_pre;
+            st_agent(ghb + j, dr_pre); st_agent(ghb + H + j, dz_pre); st_agent(ghb + 2 * H + j, dn_pre * r);
+            dhs[b * GRU_PLD + n] = g * z;
+        }
+        gru_grid_sync(counter, (unsigned)(L - t) * gridDim.x);
+        // dh_{t-1}[:, owned] = dh_t * z + dGH_t . W_hh[:, owned]
+        for (int bt = 0; bt < btiles; ++bt) {
+            const int b = bt * 32 + l31;
+            const float* grow = dgh_t + (int64_t)(b < B ? b : 0) * K3;
+            f32x16 acc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+            for (int u = 0; u < GRU_NSB / 4; ++u) {
+                if (u < nu) {                              // uniform
+                    const int k = kq0 + 8 * u + 4 * hh;
+                    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+                    if (b < B && k < K3) {                 // 3H % 4 == 0: the four k stay in range together
+                        ld_agent2(grow + k, a0, a1);
+                        ld_agent2(grow + k + 2, a2, a3);
+                    }
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, w[4 * u], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, w[4 * u + 1], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a2, w[4 * u + 2], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a3, w[4 * u + 3], acc, 0, 0, 0);
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) part[q * 32 * GRU_PLD + ((r & 3) + 8 * (r >> 2) + 4 * hh) * GRU_PLD + l31] = acc[r];
+            __syncthreads();
+            for (int e = tid; e < 32 * 32; e += 64 * GRU_WAVES) {
+                const int bb = e >> 5, n = e & 31;
+                float v = dhs[(bt * 32 + bb) * GRU_PLD + n];
+#pragma unroll
+                for (int qq = 0; qq < GRU_WAVES; ++qq) v += part[qq * 32 * GRU_PLD + bb * GRU_PLD + n];
+                dhs[(bt * 32 + bb) * GRU_PLD + n] = v;
+            }
+            __syncthreads();
+        }
+    }
+}
+
+// H <= 384 only: with one workgroup per 32 hidden units the wider models have too few workgroups for the MFMA work of a
+// step (H = 768: 24 workgroups, 26 us per step against 22 us for the gate kernel + skinny GEMM pair; H = 300: 16 us against 21)
+bool gru_seq_bwd_supported(int B, int H) { return H % 4 == 0 && H <= 384 && B >= 1 && B <= 256; }
+
+int gru_seq_bwd(const float* dh_out, const float* gates, const float* hall, const int* lens, const float* w_hh, float* dgi, float* dgh,
+                int B, int L, int H, unsigned* counter, hipStream_t s) {
+    if (hipMemsetAsync(counter, 0, 2 * sizeof(unsigned), s) != hipSuccess) { set_error("gru_seq_bwd: memset failed"); return NR_ERR_LAUNCH; }
+    int KS = ((3 * H + GRU_WAVES - 1) / GRU_WAVES + 7) / 8 * 8;
+    const int grid = cdiv(H, 32);
+    const size_t lds = (size_t)(GRU_WAVES * 32 * GRU_PLD + cdiv(B, 32) * 32 * GRU_PLD) * sizeof(float);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gru_seq_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    void* args[] = {(void*)&dh_out, (void*)&gates, (void*)&hall, (void*)&lens, (void*)&w_hh, (void*)&dgi, (void*)&dgh, (void*)&B, (void*)&L,
+                    (void*)&H, (void*)&KS, (void*)&counter};
+    ProfScope prof(FAM_GEMM, s, 2.0 * B * H * 3.0 * H * L);
+    if (hipLaunchCooperativeKernel((const void*)gru_seq_bwd_kernel, dim3(grid), dim3(64 * GRU_WAVES), args, lds, s) != hipSuccess) {
+        (void)hipGetLastError();
+        return NR_ERR_UNSUPPORTED;                         // the caller falls back to the per-step path
+    }
+    return check_launch("gru_seq_bwd");
+}
+
 int gru_lens(const int64_t* mask, int* lens, int B, int L, hipStream_t s) {
     hipLaunchKernelGGL(gru_lens_kernel, dim3(cdiv(B, 256)), dim3(256), 0, s, mask, lens, B, L);
     return check_launch("gru_lens");
