@@ -17,9 +17,24 @@ namespace nr {
 // rows for broadcast float4 reads of K/V)
 template <int DHP, int LDS_LD, int NT = 64>
 __device__ __forceinline__ void tile_to_lds(float* lds, const float* __restrict__ g, int64_t ld, int S, int dh, int lane) {
-    for (int idx = lane; idx < S * DHP; idx += NT) {
-        const int r = idx / DHP, d = idx - r * DHP;
-        lds[r * LDS_LD + d] = (d < dh) ? g[(int64_t)r * ld + d] : 0.f;
+    // eight loads in flight per lane before the first LDS store: one load per round trip made the copy the
+    // longest part of a (sequence, head) at S = 50 (a single wave has nothing else to hide the latency behind)
+    constexpr int UN = 8;
+    const int total = S * DHP;
+    for (int base = lane; base < total; base += NT * UN) {
+        float v[UN];
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+            const int idx = base + u * NT;
+            const int r = idx / DHP, d = idx - r * DHP;
+            v[u] = (idx < total && d < dh) ? g[(int64_t)r * ld + d] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+            const int idx = base + u * NT;
+            const int r = idx / DHP, d = idx - r * DHP;
+            if (idx < total) lds[r * LDS_LD + d] = v[u];
+        }
     }
 }
 template <int DHP, int LDS_LD, int NT = 64>
@@ -67,11 +82,13 @@ __global__ __launch_bounds__(NT) void mhsa_fwd_kernel(const float* __restrict__ 
     float* Vs = Ks + S * DHP;
     float* Qs = Vs + S * DHP;         // [S][LD]   (reused for the output tile)
     float* Ss = Qs + S * LD;          // [S][S+1]
+    float* Ms = Ss + S * (S + 1);     // [S] additive key mask (0 or mask_fill): one global read per key, not one per (query, key)
     const int lane = threadIdx.x;
     const int n = blockIdx.x / H, h = blockIdx.x - n * H;
     const int A = H * dh;
     const int64_t ld = 3 * (int64_t)A;
     const float* base = qkv + (int64_t)n * S * ld + h * dh;
+    if (lane < S) Ms[lane] = mask[(int64_t)n * S + lane] ? 0.f : dc.mask_fill;
     tile_to_lds<DHP, LD, NT>(Qs, base, ld, S, dh, lane);
     tile_to_lds<DHP, DHP, NT>(Ks, base + A, ld, S, dh, lane);
     tile_to_lds<DHP, DHP, NT>(Vs, base + 2 * A, ld, S, dh, lane);
@@ -89,7 +106,7 @@ __global__ __launch_bounds__(NT) void mhsa_fwd_kernel(const float* __restrict__ 
         for (int j = 0; j < S; ++j) {
             const float acc = dot_bcast<DHP>(q, Ks + j * DHP, 0.f);
             float x = acc / sq;
-            x += mask[(int64_t)n * S + j] ? 0.f : dc.mask_fill;
+            x += Ms[j];
             srow[j] = x;
             m = fmaxf(m, x);
         }
@@ -138,6 +155,7 @@ __global__ __launch_bounds__(NT) void mhsa_bwd_kernel(const float* __restrict__ 
     float* Ts = Gs + S * LD;          // staging tile for dq
     float* Ps = Ts + S * LD;          // [S][S+1] dropped probabilities
     float* Ds = Ps + S * (S + 1);     // [S][S+1] dS
+    float* Ms = Ds + S * (S + 1);     // [S] additive key mask
     const int lane = threadIdx.x;
     const int n = blockIdx.x / H, h = blockIdx.x - n * H;
     const int A = H * dh;
@@ -147,6 +165,7 @@ __global__ __launch_bounds__(NT) void mhsa_bwd_kernel(const float* __restrict__ 
     tile_to_lds<DHP, DHP, NT>(Ks, base + A, ld, S, dh, lane);
     tile_to_lds<DHP, DHP, NT>(Vs, base + 2 * A, ld, S, dh, lane);
     tile_to_lds<DHP, LD, NT>(Gs, dctx + (int64_t)n * S * A + h * dh, A, S, dh, lane);
+    if (lane < S) Ms[lane] = mask[(int64_t)n * S + lane] ? 0.f : dc.mask_fill;
     __syncthreads();
 
     const bool live = lane < S;
@@ -174,7 +193,7 @@ __global__ __launch_bounds__(NT) void mhsa_bwd_kernel(const float* __restrict__ 
                 const float acc = dot_bcast<DHP>(q, Ks + j * DHP, 0.f);
                 const float dpd = dot_bcast<DHP>(go, Vs + j * DHP, 0.f);
                 float x = acc / sq;
-                x += mask[(int64_t)n * S + j] ? 0.f : dc.mask_fill;
+                x += Ms[j];
                 const float p = expf(x - m) / sum;
                 float pd = p;
                 if (dc.p > 0.f) pd *= keep_scale(dc, thr, scale, row_linear, S, j);
@@ -231,7 +250,7 @@ int mhsa_fwd(const float* qkv, const int64_t* mask, float* ctx, float* row_max, 
     NR_UNSUPPORTED(S > 128 || S < 1, "mhsa: sequence length %d not in [1,128]", S);
     const int dhp = pick_dhp(dh);
     NR_UNSUPPORTED(dhp == 0, "mhsa: head dim %d > 128", dh);
-    const size_t lds = (size_t)(2 * S * dhp + S * (dhp + 1) + S * (S + 1)) * sizeof(float);
+    const size_t lds = (size_t)(2 * S * dhp + S * (dhp + 1) + S * (S + 1) + S) * sizeof(float);
     NR_UNSUPPORTED(lds > MHSA_LDS_MAX, "mhsa: S=%d with head dim %d needs %zu B of LDS (> %zu)", S, dh, lds, MHSA_LDS_MAX);
     ProfScope prof(FAM_ATTN, s, 4.0 * N * H * S * S * dh);
     const dim3 grid((unsigned)(N * H));
@@ -257,7 +276,7 @@ int mhsa_bwd(const float* qkv, const int64_t* mask, const float* ctx, const floa
     NR_UNSUPPORTED(S > 128 || S < 1, "mhsa bwd: sequence length %d not in [1,128]", S);
     const int dhp = pick_dhp(dh);
     NR_UNSUPPORTED(dhp == 0 || dhp > 64, "mhsa bwd: head dim %d > 64", dh);
-    const size_t lds = (size_t)(2 * S * dhp + 3 * S * (dhp + 1) + 2 * S * (S + 1)) * sizeof(float);
+    const size_t lds = (size_t)(2 * S * dhp + 3 * S * (dhp + 1) + 2 * S * (S + 1) + S) * sizeof(float);
     NR_UNSUPPORTED(lds > MHSA_LDS_MAX, "mhsa bwd: S=%d with head dim %d needs %zu B of LDS (> %zu)", S, dh, lds, MHSA_LDS_MAX);
     ProfScope prof(FAM_ATTN, s, 10.0 * N * H * S * S * dh);
     const dim3 grid((unsigned)(N * H));
