@@ -99,6 +99,16 @@ int nr_add_layernorm_fwd_f32(const float* h, const float* x, int64_t x_period, c
 size_t nr_layernorm_bwd_ws_bytes(int64_t R, int64_t D);
 int nr_add_layernorm_bwd_f32(const float* dy, const float* s, const float* mean, const float* rstd, const float* gamma, int64_t R, int64_t D, float p_drop, uint64_t seed, uint32_t site, float* ds, float* dh, float* dgamma, float* dbeta, void* ws, size_t ws_bytes, void* stream);
 
+/* The same backward for callers that cannot allocate (code under HIP graph capture, tight serving loops, harnesses
+ * that forbid hipMalloc).  NO COUNTERPART IN THE REFERENCE.  It takes no workspace: the per-block dgamma/dbeta
+ * partials live in a scratch array built into the library (nr_noalloc_scratch_bytes() = 8 MiB + 64 KiB per GPU, held
+ * until the process ends), which covers every R at D <= 1024; larger problems return NR_ERR_WORKSPACE.  It calls no
+ * hipMalloc / hipFree.  All calls on one GPU share that GPU's array: calls that overlap on one GPU (two streams,
+ * two threads) race — serialise them or use nr_add_layernorm_bwd_f32 with separate workspaces.  Results are
+ * bit-identical to nr_add_layernorm_bwd_f32 (same kernels, same reduction order). */
+size_t nr_noalloc_scratch_bytes(void);
+int nr_add_layernorm_bwd_noalloc_f32(const float* dy, const float* s, const float* mean, const float* rstd, const float* gamma, int64_t R, int64_t D, float p_drop, uint64_t seed, uint32_t site, float* ds, float* dh, float* dgamma, float* dbeta, void* stream);
+
 /* ---- multi-head self-attention core — TFMSelfAttention, attention.py:87-97 ---------------------
  * qkv [N*S, 3*H*dh] (q | k | v blocks per row), mask [N,S] (1 = real token), ctx [N*S, H*dh].
  * row_max/row_sum [N,H,S] (may be NULL in eval) are the softmax statistics the backward reuses.

@@ -286,6 +286,46 @@ int nr_add_layernorm_bwd_f32(const float* dy, const float* s_in, const float* me
     return layernorm_bwd(dy, s_in, mean, rstd, gamma, R, (int)D, DC(p_drop, seed, site), ds, dh, dgamma, dbeta, (char*)ws, S(stream));
 }
 
+// ---- the one entry point that allocates nothing (callers that cannot hipMalloc) ---------------------------------
+// The per-block dgamma/dbeta partials and the column-sum partials of the LayerNorm backward live in a file-scope
+// device array instead of a caller workspace.  Every GPU holds its own copy at its own address: the address is looked
+// up once per device (hipGetSymbolAddress with that device current) and only that pointer is ever handed to kernels.
+#define NR_NOALLOC_SCRATCH_BYTES ((size_t)(8u << 20) + (64u << 10))     /* 8 MiB + 64 KiB: D <= 1024 at any R */
+static __device__ __align__(256) unsigned char scratch[NR_NOALLOC_SCRATCH_BYTES];
+static std::mutex g_scratch_mu;
+static void* g_scratch_ptr[64] = {nullptr};                               // per device ordinal
+
+static int noalloc_scratch(char** out) {
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) { set_error("noalloc: no current HIP device (ordinal %d)", dev); return NR_ERR_LAUNCH; }
+    std::lock_guard<std::mutex> lk(g_scratch_mu);
+    if (!g_scratch_ptr[dev]) {
+        void* p = nullptr;
+        const hipError_t e = hipGetSymbolAddress(&p, HIP_SYMBOL(scratch));
+        if (e != hipSuccess || !p) { set_error("noalloc: hipGetSymbolAddress(scratch) on device %d: %s", dev, hipGetErrorString(e)); return NR_ERR_LAUNCH; }
+        g_scratch_ptr[dev] = p;
+    }
+    *out = static_cast<char*>(g_scratch_ptr[dev]);
+    return NR_OK;
+}
+
+size_t nr_noalloc_scratch_bytes(void) { return NR_NOALLOC_SCRATCH_BYTES; }
+
+int nr_add_layernorm_bwd_noalloc_f32(const float* dy, const float* s_in, const float* mean, const float* rstd, const float* gamma, int64_t R, int64_t D, float p_drop, uint64_t seed, uint32_t site, float* ds, float* dh, float* dgamma, float* dbeta, void* stream) {
+    NR_CHECK_ARG(R > 0 && D > 0, "layernorm_bwd_noalloc: bad sizes");
+    NR_CHECK_ARG(dy && s_in && mean && rstd && gamma && ds && dgamma && dbeta, "layernorm_bwd_noalloc: null pointer");
+    const size_t need = nr_layernorm_bwd_ws_bytes(R, D);
+    if (need > NR_NOALLOC_SCRATCH_BYTES) {
+        set_error("layernorm_bwd_noalloc: R=%lld D=%lld needs %zu bytes of partials, the built-in scratch holds %zu (use nr_add_layernorm_bwd_f32 with a workspace)",
+                  (long long)R, (long long)D, need, (size_t)NR_NOALLOC_SCRATCH_BYTES);
+        return NR_ERR_WORKSPACE;
+    }
+    char* ws = nullptr;
+    if (int rc = noalloc_scratch(&ws)) return rc;
+    // nothing in the scratch has to start at zero: every partial a later kernel reads is written earlier in this call
+    return layernorm_bwd(dy, s_in, mean, rstd, gamma, R, (int)D, DC(p_drop, seed, site), ds, dh, dgamma, dbeta, ws, S(stream));
+}
+
 int nr_mhsa_fwd_f32(const float* qkv, const int64_t* mask, int64_t N, int64_t Sq, int64_t H, int64_t dh, float p_drop, uint64_t seed, uint32_t site, int mask_mode, float* ctx, float* row_max, float* row_sum, void* stream) {
     NR_CHECK_ARG(N >= 0 && Sq > 0 && H > 0 && dh > 0, "mhsa_fwd: bad sizes");
     NR_CHECK_ARG(N == 0 || (qkv && mask && ctx), "mhsa_fwd: null pointer");

@@ -60,6 +60,9 @@ _SIGS = {
     "nr_layernorm_bwd_ws_bytes": (c_sz, [c_i64, c_i64]),
     "nr_add_layernorm_bwd_f32": (c_int, [c_fp, c_fp, c_fp, c_fp, c_fp, c_i64, c_i64, c_f, c_u64, c_u32,
                                          c_fp, c_fp, c_fp, c_fp, c_fp, c_sz, c_fp]),
+    "nr_noalloc_scratch_bytes": (c_sz, []),
+    "nr_add_layernorm_bwd_noalloc_f32": (c_int, [c_fp, c_fp, c_fp, c_fp, c_fp, c_i64, c_i64, c_f, c_u64, c_u32,
+                                                 c_fp, c_fp, c_fp, c_fp, c_fp]),
     "nr_mhsa_fwd_f32": (c_int, [c_fp, c_fp, c_i64, c_i64, c_i64, c_i64, c_f, c_u64, c_u32, c_int, c_fp, c_fp, c_fp, c_fp]),
     "nr_mhsa_bwd_f32": (c_int, [c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_i64, c_i64, c_i64, c_i64, c_f, c_u64, c_u32, c_int,
                                 c_fp, c_fp]),
