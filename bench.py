@@ -3,7 +3,12 @@
 multi-head self-attention layer + additive pooling, T=32, L=50, K=4, 300-d, 12 heads) on
 synthetic MIND-large-shaped data, fp32, inputs resident in HBM.
 
-    python bench.py --gpus N --steps K --warmup W          (N>1: launched by torch.distributed.run)
+    python bench.py --gpus N --steps K --warmup W
+
+N > 1: either launched by torch.distributed.run (RANK / LOCAL_RANK / WORLD_SIZE in the environment), or — when
+WORLD_SIZE is not set — bench.py starts its N ranks ITSELF, as fresh child processes created before the parent has
+made any GPU call (the reference's entry does the same with mp.spawn, main/twotower.py:55-61).  One process per GPU,
+torch.distributed "nccl" = RCCL over xGMI.
 
 One "step" = forward + backward + Adam over one batch of B impressions per GPU (B = 32, the
 reference's -bs default).  Rank 0 prints ONE JSON line: train impressions/s over all ranks
@@ -191,10 +196,111 @@ def cpu_baseline(B, steps=16):
                       "eval-mode dropout"}
 
 
+def launch_ranks(n, argv, extra_env=None, timeout=None):
+    """start `n` fresh processes of this file, one per GPU, with the torch.distributed environment (RANK, LOCAL_RANK,
+    WORLD_SIZE, MASTER_ADDR=127.0.0.1, MASTER_PORT = a free port) and wait for them.  The caller must not have touched
+    the GPU (nothing here does: no torch.cuda call is made in the parent).  Rank 0 inherits stdout, so its one JSON
+    line is this command's output.  The first rank to fail ends the others (exact PIDs).  Returns the exit status."""
+    import socket
+    import subprocess
+    sock = socket.socket()
+    sock.bind(("127.0.0.1", 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")       # the host driver only supports dmabuf IPC (RCCL needs it)
+        env.update(extra_env or {})
+        procs.append(subprocess.Popen([sys.executable, "-u", os.path.abspath(__file__)] + list(argv), env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    t0 = time.time()
+    status = 0
+    live = list(procs)
+    while live:
+        for p in list(live):
+            rc = p.poll()
+            if rc is not None:
+                live.remove(p)
+                if rc != 0 and status == 0:
+                    status = rc
+        if status != 0 or (timeout is not None and time.time() - t0 > timeout):
+            for p in live:
+                p.kill()
+            for p in live:
+                p.wait()
+            return status or 124
+        time.sleep(0.05)
+    return status
+
+
+def timed_steps(step, fence, steps, warmup, world, reduce_max):
+    """the contract's timed region: `warmup` untimed steps, then EXACTLY `steps` steps between two fences (barrier +
+    device synchronize on both sides); the time is the MAX over ranks.  Returns (seconds, last step's result)."""
+    for i in range(warmup):
+        step(i)
+    fence()
+    t0 = time.perf_counter()
+    last = None
+    for i in range(steps):
+        last = step(i)
+    fence()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        dt = reduce_max(dt)
+    return dt, last
+
+
+def stub_worker(args):
+    """CPU rehearsal of the multi-rank plumbing (tests/test_distributed_cpu.py; NR_BENCH_STUB=1): gloo instead of RCCL
+    and a tiny torch model instead of the HIP path, through the same launcher, FlatGradSync step, fences, max-over-ranks
+    timing and one-line report.  Never a measurement."""
+    world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
+    if world > 1:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    from utils.dp import FlatGradSync, all_reduce_
+    torch.manual_seed(rank)
+    model = torch.nn.Sequential(torch.nn.Linear(16, 16), torch.nn.Tanh(), torch.nn.Linear(16, 1))
+    net = FlatGradSync(model, world)
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3)
+    x = torch.randn(args.batch_size, 16)
+
+    def step(i):
+        net.zero_grad()
+        loss = net(x).square().mean()
+        loss.backward()
+        net.sync()
+        opt.step()
+        return loss
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+
+    def reduce_max(v):
+        t = torch.tensor([v], dtype=torch.float64)
+        all_reduce_(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+    dt, loss = timed_steps(step, fence, args.steps, args.warmup, world, reduce_max)
+    flat = torch.cat([p.detach().reshape(-1) for p in model.parameters()])
+    same = True
+    if world > 1:
+        both = [torch.empty_like(flat) for _ in range(world)]
+        dist.all_gather(both, flat)
+        same = all(torch.equal(both[0], b) for b in both)
+    if rank == 0:
+        print(json.dumps({"metric": "stub", "stub": True, "value": world * args.batch_size * args.steps / dt, "n_gpus": world,
+                          "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1000.0 * dt / args.steps,
+                          "replicas_identical": same, "scaling": "weak"}))
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch-size", type=int, default=32, help="impressions per GPU per step (reference -bs default)")
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="nrms",
@@ -203,9 +309,16 @@ def main():
     ap.add_argument("--gemm", choices=["fp32", "bf16"], default="fp32",
                     help="matrix-core operand precision (nr_set_gemm_compute): bf16 is the 1e-2-parity build of SURVEY §8 a7, "
                          "an extra measurement next to the fp32 headline")
+    ap.add_argument("--repeats", type=int, default=4, help="extra timed regions of --steps steps after the headline one (min/median reported)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-eval", action="store_true")
     args = ap.parse_args()
+
+    # N > 1 and not already one of N ranks: start the ranks (fresh processes; this parent never touches the GPU)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(launch_ranks(args.gpus, sys.argv[1:]))
+    if os.environ.get("NR_BENCH_STUB") == "1":
+        return stub_worker(args)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -252,7 +365,9 @@ def main():
         X = synth_train_batch(g, B, NEWS_TRAIN, ids, msk)
         batches.append({k: v.cuda() for k, v in X.items()})
 
-    def step(i):
+    ar_events = []                              # (start, end) events around the gradient all-reduce, roofline leg only
+
+    def step(i, time_sync=False):
         if world > 1:
             net.zero_grad()
         else:
@@ -260,7 +375,13 @@ def main():
         loss = net(batches[i % len(batches)])
         loss.backward()
         if world > 1:
+            if time_sync:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
             net.sync()                       # one all-reduce (average) over the flat gradient buffer
+            if time_sync:
+                e1.record()                  # the current stream waits for the collective, so the pair brackets it
+                ar_events.append((e0, e1))
         opt.step()
         return loss
 
@@ -270,27 +391,34 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    for i in range(args.warmup):
-        step(i)
-    fence()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        loss = step(i)
-    fence()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        tt = torch.tensor([dt], device="cuda", dtype=torch.float64)
+    def reduce_max(v):
+        tt = torch.tensor([v] if not isinstance(v, (list, tuple)) else list(v), device="cuda", dtype=torch.float64)
         all_reduce_(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
+        out = [float(x) for x in tt.tolist()]
+        return out if isinstance(v, (list, tuple)) else out[0]
+
+    dt, loss = timed_steps(step, fence, args.steps, args.warmup, world, reduce_max)
     final_loss = float(loss)
     ms_per_step = 1000.0 * dt / args.steps
     value = world * B * args.steps / dt
+    # the same region again, --repeats times (reported next to the headline, never instead of it: VERDICT r1 item 8)
+    rep = []
+    for _ in range(args.repeats):
+        d, _l = timed_steps(step, fence, args.steps, 0, world, reduce_max)
+        rep.append(1000.0 * d / args.steps)
 
     # ---- roofline leg: same steps with HIP events around every launch of each kernel family
     ops.prof_enable(True)
     for i in range(args.steps):
-        step(i)
+        step(i, time_sync=True)
     torch.cuda.synchronize()
+    allreduce = None
+    if world > 1:
+        ar_ms = sum(a.elapsed_time(b) for a, b in ar_events) / max(len(ar_events), 1)
+        nbytes = net.flat.numel() * 4
+        allreduce = {"ms_per_step": round(ar_ms, 4), "frac_of_step": round(ar_ms / ms_per_step, 4), "bytes": nbytes,
+                     "algbw_GB/s": round(nbytes / (ar_ms * 1e-3) / 1e9, 1) if ar_ms > 0 else None,
+                     "backend": dist.get_backend(), "note": "events around FlatGradSync.sync (one flat all-reduce + 1/N scale) on rank 0"}
     fam = {}
     for name, idx in (("gemm", 0), ("gather", 1), ("attention", 2), ("layernorm", 3), ("pool", 4), ("score", 5), ("misc", 6), ("scatter_add", 7)):
         ms, n, work = ops.prof_read(idx)
@@ -326,6 +454,9 @@ def main():
         "config": {"workload": WORKLOADS[args.workload][4] + ", train step = fwd+bwd+Adam with dropout 0.1",
                    "per_gpu_batch": B, "global_batch": B * world, "vocab": V, "parallelism": f"dp{world}"},
         "loss": round(final_loss, 5),
+        "repeats_ms_per_step": {"n": len(rep), "min": round(min(rep), 4), "median": round(sorted(rep)[len(rep) // 2], 4),
+                                "max": round(max(rep), 4)} if rep else None,
+        "allreduce": allreduce,
         "model_tflops": round(value * train_flops_per_impression() / 1e12, 2) if not extra else None,
         "roofline": roofline, "hbm_kernels": hbm, "hbm_families_in_step": hbm_step, "kernel_ms_per_step": {k: v["ms_per_step"] for k, v in fam.items()},
     }
@@ -334,27 +465,26 @@ def main():
     if not args.no_eval:
         try:                               # a secondary leg: its failure must not take the headline line with it
             model.eval()
+            import numpy as np
+            import types
             gd = torch.Generator().manual_seed(7)
             dids, dmsk = synth_table(gd, NEWS_DEV)
-            dids, dmsk = dids.cuda(), dmsk.cuda()
-            lo, hi = round(NEWS_DEV / world * rank), round(NEWS_DEV / world * (rank + 1))
+            # the product's own cache build: TwoTowerBaseModel.encode_news shards the corpus rows over the ranks, encodes
+            # its slice and all-gathers the [Nn, D] table (dist.all_gather_into_tensor on RCCL); the token table is
+            # attached in HBM first (inputs resident before the timed region)
+            news_ds = types.SimpleNamespace(token_ids=dids.numpy(), attn_masks=dmsk.numpy())
+            loader_news = types.SimpleNamespace(dataset=type("NewsRows", (), {"__len__": lambda self: NEWS_DEV, "token_ids": news_ds.token_ids,
+                                                                             "attn_masks": news_ds.attn_masks})(), batch_size=200)
+            mgr.distributed, mgr.world_size, mgr.rank = world > 1, world, rank
+            model.world_size, model.rank = world, rank
+            model.attach_news_corpus(dids, dmsk)
             with torch.no_grad():
-                def encode():
-                    outs = []
-                    for s in range(lo, hi, 8192):
-                        outs.append(model.newsEncoder(dids[s:min(hi, s + 8192)], dmsk[s:min(hi, s + 8192)])[1])
-                    return torch.cat(outs)
-                encode()
+                model.encode_news(mgr, loader_news)
                 fence()
                 t0 = time.perf_counter()
-                part = encode()
+                model.encode_news(mgr, loader_news)
                 fence()
                 t_enc = time.perf_counter() - t0
-                cache = torch.zeros(NEWS_DEV, D, device="cuda")
-                cache[lo:hi] = part
-                if world > 1:
-                    all_reduce_(cache)
-                model.news_embeddings = cache
                 Re, Ce = 200, 20
                 rows = []
                 for _ in range(8):
@@ -389,11 +519,22 @@ def main():
                 lab_all, valid_d, impr_d = lab_all.cuda(), valid.cuda(), impr_of_row.cuda()
                 hm = torch.ones(8192, L, dtype=torch.int64, device="cuda")
 
+                # this rank's impressions as a list of 8192-row batches = the "loader" of the product's own _predict, which
+                # scores them (infer), keeps the results on the device and, for N > 1, gathers them to rank 0 as flat typed
+                # tensors; rank 0 then computes the per-impression metrics on the device.  Impression ids are made
+                # distinct across ranks (rank * n_impr + i) as the reference's shards are.
+                impr_g = impr_d + rank * n_impr
+                eval_loader = [{"cdd_idx": cdd_all[s:s + 8192], "his_idx": his_all[s:s + 8192], "his_mask": hm[:min(8192, Rtot - s)],
+                                "impr_index": impr_g[s:s + 8192], "cdd_mask": valid_d[s:s + 8192], "label": lab_all[s:s + 8192]}
+                               for s in range(0, Rtot, 8192)]
+                mgr.impr_size = Ce
+
                 def full_eval():
-                    preds = [model.infer({"cdd_idx": cdd_all[s:s + 8192], "his_idx": his_all[s:s + 8192], "his_mask": hm[:min(8192, Rtot - s)],
-                                          "impr_index": impr_d[s:s + 8192]})
-                             for s in range(0, Rtot, 8192)]
-                    return device_compute_metrics(impr_d, valid_d, torch.cat(preds), lab_all, ["auc", "mean_mrr", "ndcg@5;10"])
+                    res = model._predict(mgr, eval_loader, with_labels=True, to_host=False)
+                    if res is None:
+                        return None
+                    impr, masks, preds, labels = res
+                    return device_compute_metrics(impr, masks, preds, labels, ["auc", "mean_mrr", "ndcg@5;10"])
                 full_eval()
                 fence()
                 t0 = time.perf_counter()
@@ -401,16 +542,15 @@ def main():
                 fence()
                 t_full = time.perf_counter() - t0
             if world > 1:
-                tt = torch.tensor([t_enc, t_inf, t_full], device="cuda", dtype=torch.float64)
-                all_reduce_(tt, op=dist.ReduceOp.MAX)
-                t_enc, t_inf, t_full = [float(v) for v in tt.tolist()]
+                t_enc, t_inf, t_full = reduce_max([t_enc, t_inf, t_full])
             out["eval"] = {"news_cache_rows": NEWS_DEV, "cache_build_news_per_s": round(NEWS_DEV / t_enc, 1),
                            "infer_rows_per_s_batch200": round(world * n_it * Re / t_inf, 1),
                            "eval_impressions_per_s": round(world * n_impr / t_full, 1),
                            "eval_rows_per_s": round(world * Rtot / t_full, 1),
-                           "note": "cache build = this rank's shard of the 72 024-news corpus (tfm encoder); batch200 = the reference's "
-                                   "-bse default; eval_impressions_per_s = 40 000 impressions per GPU (2..80 candidates, L=50, tfm user "
-                                   "encoder) scored in 8192-row batches + device AUC/MRR/nDCG@5/10, end to end",
+                           "note": "cache build = TwoTowerBaseModel.encode_news over the 72 024-news corpus (sharded over the ranks + "
+                                   "all-gather, tfm encoder); batch200 = the reference's -bse default; eval_impressions_per_s = 40 000 "
+                                   "impressions per GPU (2..80 candidates, L=50, tfm user encoder) through _predict (8192-row batches, "
+                                   "typed gather to rank 0) + device AUC/MRR/nDCG@5/10 on rank 0, end to end",
                            "metrics_of_random_scores": met}
 
         except Exception as e:                 # noqa: BLE001 — reported in the JSON line

@@ -198,6 +198,15 @@ int nr_gru_fwd_f32(const float* x, const int64_t* mask, const float* w_ih, const
 size_t nr_gru_bwd_ws_bytes(int64_t B, int64_t L, int64_t Din, int64_t H);
 int nr_gru_bwd_f32(const float* dh_out, const float* x, const float* w_ih, const float* w_hh, int64_t B, int64_t L, int64_t Din, int64_t H, const float* hall, const float* gates, const int32_t* lens, float* dx, float* dw_ih, float* dw_hh, float* db_ih, float* db_hh, void* ws, size_t ws_bytes, void* stream);
 
+/* The persistent recurrences synchronise their workgroups with a grid barrier whose spin is bounded (2^22 polls, seconds),
+ * so a lost workgroup cannot hang the GPU.  A workgroup that gives up overwrites the outputs it owns with NaN (hall[L]
+ * columns in the forward, dGI columns -> dw_ih / dx in the backward: the loss or the gradients turn NaN) and raises a flag
+ * at the head of the workspace.  nr_gru_status synchronises `stream`, reads that flag from the `ws` of the LAST
+ * nr_gru_fwd_f32 / nr_gru_bwd_f32 call that used it and returns NR_ERR_LAUNCH if the barrier timed out, NR_OK otherwise.
+ * nr_gru_debug_set_spin_limit is a TEST HOOK (process-wide): polls before giving up; 0 restores the default. */
+int nr_gru_status(const void* ws, void* stream);
+int nr_gru_debug_set_spin_limit(uint32_t polls);
+
 /* ---- per-impression ranking metrics — pack_results + compute_metrics, utils/util.py:37-57,126-158,197-250 ----
  * Result rows (<= Ce-candidate chunks of an impression, models/BaseModel.py:254-260) stay in HBM as flat tensors:
  * preds [R,Ce] f32, labels [R,Ce] int64 (-1 = padding), masks [R,Ce] uint8.  Impression g = rows

@@ -574,6 +574,7 @@ int nr_gru_fwd_f32(const float* x, const int64_t* mask, const float* w_ih, const
     // input half of every step in one GEMM: GI[b*L+t, :] = x[b,t,:] W_ih^T + b_ih
     if (int rc = linear_fwd(x, Din, w_ih, b_ih, B * L, Din, 3 * H, EPI_NONE, gi, nullptr, s)) return rc;
     // the recurrence: one persistent launch when the shape allows it (the counter lives at the head of the workspace) ...
+    if (ws && ws_bytes >= 256 && hipMemsetAsync(ws, 0, 2 * sizeof(unsigned), s) != hipSuccess) { set_error("gru_fwd: memset failed"); return NR_ERR_LAUNCH; }
     if (ws && ws_bytes >= 256 && gru_seq_fwd_supported((int)B, (int)H) && !g_gru_per_step) {
         const int rc = gru_seq_fwd(gi, w_hh, b_hh, lens, hall, gates, (int)B, (int)L, (int)H, (unsigned*)ws, s);
         if (rc != NR_ERR_UNSUPPORTED) return rc;
@@ -604,11 +605,12 @@ int nr_gru_bwd_f32(const float* dh_out, const float* x, const float* w_ih, const
     NR_CHECK_ARG(ws && ws_bytes >= nr_gru_bwd_ws_bytes(B, L, Din, H), "gru_bwd: workspace too small");
     hipStream_t s = S(stream);
     char* cur = (char*)ws;
+    unsigned* counter = reinterpret_cast<unsigned*>(bump(cur, 64));   // head of the workspace: nr_gru_status reads it
+    if (hipMemsetAsync(counter, 0, 2 * sizeof(unsigned), s) != hipSuccess) { set_error("gru_bwd: memset failed"); return NR_ERR_LAUNCH; }
     float* dgi = bump(cur, (size_t)B * L * 3 * H);           // rows b*L + t  (the order of x)
     float* dgh = bump(cur, (size_t)B * L * 3 * H);           // rows t*B + b  (the order of hall)
     float* direct = bump(cur, (size_t)B * H);                 // dh_t * z
     float* pp[2] = {bump(cur, (size_t)B * H), bump(cur, (size_t)B * H)};
-    unsigned* counter = reinterpret_cast<unsigned*>(bump(cur, 64));
     const size_t rest = ws_bytes - (size_t)(cur - (char*)ws);
     const float* dh = dh_out;
     int k = 0;
@@ -635,6 +637,23 @@ int nr_gru_bwd_f32(const float* dh_out, const float* x, const float* w_ih, const
     if (dx) return linear_bwd_input(dgi, 3 * H, w_ih, B * L, 3 * H, Din, EPI_NONE, nullptr, nullptr, dx, s);
     return NR_OK;
 }
+
+int nr_gru_status(const void* ws, void* stream) {
+    NR_CHECK_ARG(ws, "gru_status: null workspace");
+    unsigned host[2] = {0, 0};
+    if (hipStreamSynchronize(S(stream)) != hipSuccess || hipMemcpy(host, ws, sizeof(host), hipMemcpyDeviceToHost) != hipSuccess) {
+        set_error("gru_status: %s", hipGetErrorString(hipGetLastError()));
+        return NR_ERR_LAUNCH;
+    }
+    if (host[1] != 0) {
+        set_error("gru: the grid barrier of the persistent recurrence timed out (a workgroup never arrived); the outputs of the "
+                  "workgroups that gave up were overwritten with NaN");
+        return NR_ERR_LAUNCH;
+    }
+    return NR_OK;
+}
+
+int nr_gru_debug_set_spin_limit(uint32_t polls) { gru_set_spin_limit(polls ? polls : (1u << 22)); return NR_OK; }
 
 // ------------------------------------------------------------------------------------ evaluation metrics
 int nr_impression_metrics_f64(const float* preds, const int64_t* labels, const uint8_t* masks, int64_t Ce, const int64_t* row_start,

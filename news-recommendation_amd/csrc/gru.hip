@@ -106,15 +106,19 @@ __device__ __forceinline__ void ld_agent2(const float* p, float& a, float& b) { 
     b = __builtin_bit_cast(float, (unsigned)(v >> 32));
 }
 
-__device__ __forceinline__ void gru_grid_sync(unsigned* counter, unsigned target) {
+// Grid barrier with a bounded spin.  A workgroup that gives up (a lost or never-scheduled peer) raises counter[1]
+// (read back by nr_gru_status) AND remembers it in *timed_out (LDS): before the kernel ends, that workgroup overwrites
+// the outputs it owns with NaN, so the failure reaches the loss / the gradients instead of passing as stale numbers.
+__device__ __forceinline__ void gru_grid_sync(unsigned* counter, unsigned target, unsigned spin_limit, int* timed_out) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this wave's state stores have reached the coherence point
     __syncthreads();
     if (threadIdx.x == 0) {
         __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         unsigned spins = 0;
         while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
-            if (++spins > (1u << 22)) {                    // ~seconds: give up loudly rather than hang
+            if (spins++ >= spin_limit) {                   // default 2^22 polls ~ seconds: give up rather than hang
                 __hip_atomic_store(counter + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                *timed_out = 1;
                 break;
             }
             __builtin_amdgcn_s_sleep(1);
@@ -123,11 +127,17 @@ __device__ __forceinline__ void gru_grid_sync(unsigned* counter, unsigned target
     __syncthreads();
 }
 
+static unsigned g_gru_spin_limit = 1u << 22;
+void gru_set_spin_limit(unsigned polls) { g_gru_spin_limit = polls; }
+
 __global__ __launch_bounds__(64 * GRU_WAVES) void gru_seq_fwd_kernel(const float* __restrict__ gi, const float* __restrict__ w_hh,
                                                                     const float* __restrict__ b_hh, const int* __restrict__ lens,
                                                                     float* hall, float* __restrict__ gates, int B, int L, int H,
-                                                                    int KS, unsigned* counter) {
+                                                                    int KS, unsigned* counter, unsigned spin_limit) {
     __shared__ float part[GRU_WAVES][32 * GRU_PLD];
+    __shared__ int timed_out;
+    if (threadIdx.x == 0) timed_out = 0;
+    __syncthreads();
     const int tid = threadIdx.x, lane = tid & 63;
     const int q = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, hh = lane >> 5;
@@ -208,7 +218,14 @@ __global__ __launch_bounds__(64 * GRU_WAVES) void gru_seq_fwd_kernel(const float
             }
             __syncthreads();
         }
-        if (t + 1 < L) gru_grid_sync(counter, (unsigned)(t + 1) * gridDim.x);
+        if (t + 1 < L) gru_grid_sync(counter, (unsigned)(t + 1) * gridDim.x, spin_limit, &timed_out);
+    }
+    if (timed_out) {                                       // block-uniform (read after the barrier's __syncthreads)
+        float* hl = hall + (size_t)L * B * H;
+        for (int e = tid; e < B * GRU_U; e += 64 * GRU_WAVES) {
+            const int b2 = e / GRU_U, j = j0 + e % GRU_U;
+            if (j < H) st_agent(hl + (int64_t)b2 * H + j, __builtin_nanf(""));
+        }
     }
 }
 
@@ -219,9 +236,10 @@ int gru_seq_fwd(const float* gi, const float* w_hh, const float* b_hh, const int
                 unsigned* counter, hipStream_t s) {
     if (hipMemsetAsync(counter, 0, 2 * sizeof(unsigned), s) != hipSuccess) { set_error("gru_seq_fwd: memset failed"); return NR_ERR_LAUNCH; }
     int KS = ((H + GRU_WAVES - 1) / GRU_WAVES + 7) / 8 * 8;
+    unsigned spin_limit = g_gru_spin_limit;
     const int grid = cdiv(H, GRU_U);
     void* args[] = {(void*)&gi, (void*)&w_hh, (void*)&b_hh, (void*)&lens, (void*)&hall, (void*)&gates, (void*)&B, (void*)&L, (void*)&H,
-                    (void*)&KS, (void*)&counter};
+                    (void*)&KS, (void*)&counter, (void*)&spin_limit};
     ProfScope prof(FAM_GEMM, s, 2.0 * B * H * 3.0 * H * L);
     if (hipLaunchCooperativeKernel((const void*)gru_seq_fwd_kernel, dim3(grid), dim3(64 * GRU_WAVES), args, 0, s) != hipSuccess) {
         (void)hipGetLastError();
@@ -241,8 +259,11 @@ constexpr int GRU_NSB = 48;          // MFMAs per wave and batch tile at most: k
 __global__ __launch_bounds__(64 * GRU_WAVES) void gru_seq_bwd_kernel(const float* __restrict__ dh_out, const float* __restrict__ gates,
                                                                     const float* __restrict__ hall, const int* __restrict__ lens,
                                                                     const float* __restrict__ w_hh, float* __restrict__ dgi,
-                                                                    float* dgh, int B, int L, int H, int KS, unsigned* counter) {
+                                                                    float* dgh, int B, int L, int H, int KS, unsigned* counter,
+                                                                    unsigned spin_limit) {
     extern __shared__ float gsm[];
+    __shared__ int timed_out;
+    if (threadIdx.x == 0) timed_out = 0;
     float* part = gsm;                                   // [12][32 * 33]
     float* dhs = gsm + GRU_WAVES * 32 * GRU_PLD;         // [ceil(B/32)*32][33]: dh_t, then dh_t * z, then dh_{t-1}
     const int tid = threadIdx.x, lane = tid & 63;
@@ -295,7 +316,7 @@ __global__ __launch_bounds__(64 * GRU_WAVES) void gru_seq_bwd_kernel(const float
             st_agent(ghb + j, dr_pre); st_agent(ghb + H + j, dz_pre); st_agent(ghb + 2 * H + j, dn_pre * r);
             dhs[b * GRU_PLD + n] = g * z;
         }
-        gru_grid_sync(counter, (unsigned)(L - t) * gridDim.x);
+        gru_grid_sync(counter, (unsigned)(L - t) * gridDim.x, spin_limit, &timed_out);
         // dh_{t-1}[:, owned] = dh_t * z + dGH_t . W_hh[:, owned]
         for (int bt = 0; bt < btiles; ++bt) {
             const int b = bt * 32 + l31;
@@ -331,6 +352,12 @@ __global__ __launch_bounds__(64 * GRU_WAVES) void gru_seq_bwd_kernel(const float
             __syncthreads();
         }
     }
+    if (timed_out) {                                       // poison this workgroup's columns of dGI (-> dW_ih, dx become NaN)
+        for (int e = tid; e < B * 32; e += 64 * GRU_WAVES) {
+            const int b = e >> 5, j = j0 + (e & 31);
+            if (j < H) dgi[((int64_t)b * L) * K3 + j] = __builtin_nanf("");
+        }
+    }
 }
 
 // H <= 384 only: with one workgroup per 32 hidden units the wider models have too few workgroups for the MFMA work of a
@@ -341,11 +368,12 @@ int gru_seq_bwd(const float* dh_out, const float* gates, const float* hall, cons
                 int B, int L, int H, unsigned* counter, hipStream_t s) {
     if (hipMemsetAsync(counter, 0, 2 * sizeof(unsigned), s) != hipSuccess) { set_error("gru_seq_bwd: memset failed"); return NR_ERR_LAUNCH; }
     int KS = ((3 * H + GRU_WAVES - 1) / GRU_WAVES + 7) / 8 * 8;
+    unsigned spin_limit = g_gru_spin_limit;
     const int grid = cdiv(H, 32);
     const size_t lds = (size_t)(GRU_WAVES * 32 * GRU_PLD + cdiv(B, 32) * 32 * GRU_PLD) * sizeof(float);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gru_seq_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     void* args[] = {(void*)&dh_out, (void*)&gates, (void*)&hall, (void*)&lens, (void*)&w_hh, (void*)&dgi, (void*)&dgh, (void*)&B, (void*)&L,
-                    (void*)&H, (void*)&KS, (void*)&counter};
+                    (void*)&H, (void*)&KS, (void*)&counter, (void*)&spin_limit};
     ProfScope prof(FAM_GEMM, s, 2.0 * B * H * 3.0 * H * L);
     if (hipLaunchCooperativeKernel((const void*)gru_seq_bwd_kernel, dim3(grid), dim3(64 * GRU_WAVES), args, lds, s) != hipSuccess) {
         (void)hipGetLastError();

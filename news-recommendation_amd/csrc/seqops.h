@@ -34,6 +34,7 @@ int seq_broadcast(const float* dout, float* dx, int64_t nseq, int S, int D, floa
 // GRU recurrence (gru.hip): one persistent launch for the whole forward, or the per-step halves
 bool gru_seq_fwd_supported(int B, int H);
 bool gru_seq_bwd_supported(int B, int H);
+void gru_set_spin_limit(unsigned polls);
 int gru_seq_bwd(const float* dh_out, const float* gates, const float* hall, const int* lens, const float* w_hh, float* dgi, float* dgh,
                 int B, int L, int H, unsigned* counter, hipStream_t s);
 int gru_seq_fwd(const float* gi, const float* w_hh, const float* b_hh, const int* lens, float* hall, float* gates, int B, int L, int H,

@@ -24,6 +24,7 @@ import torch.distributed as dist
 from tqdm import tqdm
 
 from newsrec_hip import ops
+from utils.dp import all_gather_into_tensor_, all_gather_list
 from utils.util import pack_results, compute_metrics, device_compute_metrics, HipAdam, linear_warmup_lambda
 
 
@@ -97,7 +98,7 @@ class BaseModel(nn.Module):
 
 
 def _barrier(device):
-    if isinstance(device, int):
+    if isinstance(device, int) and dist.get_backend() == "nccl":
         dist.barrier(device_ids=[device])
     else:
         dist.barrier()
@@ -106,14 +107,11 @@ def _barrier(device):
 def _gather_to_rank0(t, world_size, rank):
     """variable-length typed gather: returns the list of every rank's tensor on rank 0 (else None)."""
     n = torch.tensor([t.shape[0]], dtype=torch.int64, device=t.device)
-    sizes = [torch.zeros_like(n) for _ in range(world_size)]
-    dist.all_gather(sizes, n)
-    sizes = [int(s.item()) for s in sizes]
+    sizes = [int(s.item()) for s in all_gather_list(n, world_size)]
     cap = max(sizes)
     pad = t.new_zeros((cap,) + tuple(t.shape[1:]))
     pad[:t.shape[0]] = t
-    bufs = [torch.empty_like(pad) for _ in range(world_size)]
-    dist.all_gather(bufs, pad)
+    bufs = all_gather_list(pad, world_size)
     if rank != 0:
         return None
     return [b[:s] for b, s in zip(bufs, sizes)]
@@ -138,6 +136,13 @@ class TwoTowerBaseModel(BaseModel):
         as_t = lambda a: a if isinstance(a, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(a))
         self._news_token_ids = as_t(token_ids).to(self.device).long().contiguous()
         self._news_attn_masks = as_t(attn_masks).to(self.device).long().contiguous()
+
+    def attach_news_corpus(self, token_ids, attn_masks):
+        """the same for the rows of the MIND_News set that encode_news walks (the dev / test corpus, not the training
+        one): encode_news then slices them on the device instead of copying every chunk from the host."""
+        as_t = lambda a: a if isinstance(a, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(a))
+        self._corpus_token_ids = as_t(token_ids).to(self.device).long().contiguous()
+        self._corpus_attn_masks = as_t(attn_masks).to(self.device).long().contiguous()
 
     def _tokens(self, x, key):
         """(token_id, attn_mask) of the `key` ("cdd" | "his") titles of a batch, on the device"""
@@ -231,9 +236,14 @@ class TwoTowerBaseModel(BaseModel):
         local = torch.zeros((hi - lo, self.hidden_dim), dtype=torch.float32, device=self.device)
         chunk = int(getattr(manager, "encode_chunk", 8192))
         stop = min(hi, lo + 7 * loader_news.batch_size) if manager.debug else hi      # --debug: first 7 batches only
+        tok = getattr(self, "_corpus_token_ids", None)       # attach_news_corpus(): the table is already in HBM
+        on_dev = tok is not None and tok.shape[0] == Nn
         for s in tqdm(range(lo, stop, chunk), ncols=80, desc="Encoding News", disable=self.rank != 0):
             e = min(stop, s + chunk)
-            x = {"cdd_token_id": torch.from_numpy(ds.token_ids[s:e]), "cdd_attn_mask": torch.from_numpy(ds.attn_masks[s:e])}
+            if on_dev:
+                x = {"cdd_token_id": tok[s:e], "cdd_attn_mask": self._corpus_attn_masks[s:e]}
+            else:
+                x = {"cdd_token_id": torch.from_numpy(ds.token_ids[s:e]), "cdd_attn_mask": torch.from_numpy(ds.attn_masks[s:e])}
             _, emb = self._encode_news(x)
             local[s - lo:e - lo] = emb
         if manager.distributed:
@@ -241,7 +251,7 @@ class TwoTowerBaseModel(BaseModel):
             pad = torch.zeros((cap, self.hidden_dim), dtype=torch.float32, device=self.device)
             pad[:hi - lo] = local
             gathered = torch.empty((ws * cap, self.hidden_dim), dtype=torch.float32, device=self.device)
-            dist.all_gather_into_tensor(gathered, pad)
+            all_gather_into_tensor_(gathered, pad)
             parts = [gathered[r * cap: r * cap + round(per * (r + 1)) - round(per * r)] for r in range(ws)]
             self.news_embeddings = torch.cat(parts, 0).contiguous()
         else:

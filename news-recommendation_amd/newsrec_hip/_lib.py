@@ -87,6 +87,8 @@ _SIGS = {
     "nr_gru_bwd_ws_bytes": (c_sz, [c_i64, c_i64, c_i64, c_i64]),
     "nr_gru_bwd_f32": (c_int, [c_fp, c_fp, c_fp, c_fp, c_i64, c_i64, c_i64, c_i64, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp,
                                c_fp, c_sz, c_fp]),
+    "nr_gru_status": (c_int, [c_fp, c_fp]),
+    "nr_gru_debug_set_spin_limit": (c_int, [c_u32]),
     "nr_impression_metrics_f64": (c_int, [c_fp, c_fp, c_fp, c_i64, c_fp, c_fp, c_i64, c_int, C.POINTER(c_int), c_fp, c_fp, c_fp]),
     "nr_dropout_f32": (c_int, [c_fp, c_i64, c_f, c_u64, c_u32, c_fp, c_fp]),
     "nr_add_bias_rows_f32": (c_int, [c_fp, c_fp, c_i64, c_i64, c_fp, c_fp]),

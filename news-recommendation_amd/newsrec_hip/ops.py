@@ -292,6 +292,16 @@ def tfm_layer(x, mask, head_num, params, p_drop=0.0, seed=0, site=0, hf_mask=Fal
 
 
 # ----------------------------------------------------------------------------- GRU user encoder
+_last_gru_ws = None      # workspace of the most recent GRU call (its head holds the barrier-timeout flag)
+
+
+def gru_status():
+    """raise NewsrecError if the grid barrier of the most recent persistent GRU launch timed out (host sync; the
+    outputs of a timed-out launch are NaN-poisoned anyway, this names the cause)."""
+    if _last_gru_ws is not None:
+        check(lib().nr_gru_status(_p(_last_gru_ws), _stream()), "nr_gru_status")
+
+
 class _GRUFinal(torch.autograd.Function):
     """final state of nn.GRU over a packed batch (RnnUserEncoder.forward, encoder.py:216-233)."""
 
@@ -309,6 +319,8 @@ class _GRUFinal(torch.autograd.Function):
         ws = _ws(lib().nr_gru_fwd_ws_bytes(B, H), dev)
         check(lib().nr_gru_fwd_f32(_p(x), _p(mask), _p(w_ih), _p(w_hh), _p(b_ih), _p(b_hh), B, L, Din, H, _p(gi), _p(gh), _p(hall),
                                    _p(gates), _p(lens), _p(ws), ws.numel() * 4, _stream()), "nr_gru_fwd_f32")
+        global _last_gru_ws
+        _last_gru_ws = ws
         if train:
             ctx.save_for_backward(x, w_ih, w_hh, hall, gates, lens)
         return hall[L].clone()
@@ -328,6 +340,8 @@ class _GRUFinal(torch.autograd.Function):
         ws = _ws(Lb.nr_gru_bwd_ws_bytes(B, L, Din, H), dev)
         check(Lb.nr_gru_bwd_f32(_p(g), _p(x), _p(w_ih), _p(w_hh), B, L, Din, H, _p(hall), _p(gates), _p(lens), _p(dx), _p(dw_ih),
                                 _p(dw_hh), _p(db_ih), _p(db_hh), _p(ws), ws.numel() * 4, _stream()), "nr_gru_bwd_f32")
+        global _last_gru_ws
+        _last_gru_ws = ws
         return dx, None, dw_ih, dw_hh, db_ih, db_hh
 
 

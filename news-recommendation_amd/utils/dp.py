@@ -2,18 +2,25 @@
 
 The reference wraps the model in DistributedDataParallel (main/twotower.py:40-41).  Here every parameter's
 .grad is a view into ONE flat fp32 buffer and the step is: zero the buffer -> backward accumulates in place ->
-one all-reduce (average) over the buffer -> Adam.  No autograd hooks and no communication thread running beside
-the backward: of the 46 MB reduced per step at 300-d, 36.6 MB are the dense token-table gradient, which is the
-LAST thing the backward produces, so bucket overlap had little to hide — and the hook-driven reducer deadlocked
-against this library's launches in multi-step rehearsals (tools/ddp_steps.py).
+one all-reduce (average) over the buffer -> Adam.  No autograd hooks and no communication thread beside the
+backward.  The design reason: of the 46 MB reduced per step at 300-d, 36.6 MB are the dense token-table gradient,
+which is the LAST thing the backward produces, so DDP's bucket overlap had ~10 MB to hide, and one large collective
+uses the xGMI links better than several 25 MB buckets.
+
+What is known about DistributedDataParallel with this library (round 1 records, gpurun_out/ddp_steps_*): wrapped in
+torch's DDP over GLOO with TWO PROCESSES ON ONE GPU, both ranks stalled in the first backward (main thread in
+_engine_run_backward, the autograd engine thread inside C++ with no Python frame); a stock torch model passed in the
+same set-up (ddp_plain.log).  The cause was not established and that configuration (gloo, a shared GPU, the
+hook-driven reducer) is not a target: FlatGradSync is the product's data-parallel path by design, not a diagnosis of
+that stall.  DDP over RCCL with one process per GPU has not been run with this library.
 """
 import torch
 import torch.distributed as dist
 
 
 def _staged(t):
-    """gloo's own path for device tensors proved unreliable with two processes on one GPU (rehearsals hung inside
-    plain broadcasts): under gloo, collectives on device tensors go through a host copy.  RCCL ("nccl") is untouched."""
+    """under gloo (CPU tests, the one-GPU rehearsal of bench.py) collectives on device tensors go through an explicit
+    host copy, so the rehearsal exercises only gloo's host path.  RCCL ("nccl") is untouched."""
     return t.is_cuda and dist.get_backend() == "gloo"
 
 
@@ -35,6 +42,28 @@ def broadcast_(t, src=0):
     else:
         dist.broadcast(t, src)
     return t
+
+
+def all_gather_into_tensor_(out, t):
+    """out [world * n, ...] <- every rank's t [n, ...] (rank-major), the collective of the sharded news-cache build"""
+    if _staged(t):
+        co = torch.empty(out.shape, dtype=out.dtype)
+        dist.all_gather_into_tensor(co, t.cpu())
+        out.copy_(co)
+    else:
+        dist.all_gather_into_tensor(out, t)
+    return out
+
+
+def all_gather_list(t, world):
+    """list of every rank's tensor (all of t's shape)"""
+    if _staged(t):
+        bufs = [torch.empty(t.shape, dtype=t.dtype) for _ in range(world)]
+        dist.all_gather(bufs, t.cpu())
+        return [b.to(t.device) for b in bufs]
+    bufs = [torch.empty_like(t) for _ in range(world)]
+    dist.all_gather(bufs, t)
+    return bufs
 
 
 class FlatGradSync(torch.nn.Module):

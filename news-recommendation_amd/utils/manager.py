@@ -169,7 +169,7 @@ class Manager():
 
     def barrier(self):
         if self.distributed:
-            if isinstance(self.device, int):
+            if isinstance(self.device, int) and dist.get_backend() == "nccl":
                 dist.barrier(device_ids=[self.device])
             else:
                 dist.barrier()

@@ -149,3 +149,39 @@ def test_flat_grad_sync_two_ranks():
         assert same, "replicas diverged"
         assert err < 1e-6, err
         assert views
+
+
+@pytest.mark.timeout(300)
+def test_bench_launcher_starts_its_own_ranks():
+    """`python bench.py --gpus 2` with no WORLD_SIZE in the environment must start 2 ranks itself (fresh processes,
+    torch.distributed environment on 127.0.0.1) and rank 0 must print ONE JSON line with n_gpus = 2.  NR_BENCH_STUB=1
+    swaps the HIP step for a tiny torch model on gloo; the launcher, FlatGradSync step, fences, max-over-ranks timing
+    and report are bench.py's own."""
+    import json
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env["NR_BENCH_STUB"] = "1"
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "2", "--batch-size", "4"],
+                       env=env, capture_output=True, text=True, timeout=240)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["steps"] == 6 and out["warmup"] == 2 and out["stub"] is True
+    assert out["replicas_identical"] and out["value"] > 0 and out["ms_per_step"] > 0
+    # --gpus 1 stays in-process (no launcher, no process group)
+    r1 = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1", "--batch-size", "4"],
+                        env=env, capture_output=True, text=True, timeout=240)
+    assert r1.returncode == 0, r1.stderr[-2000:]
+    assert json.loads([l for l in r1.stdout.splitlines() if l.startswith("{")][0])["n_gpus"] == 1
+
+
+def test_bench_launcher_propagates_a_rank_failure():
+    """a rank that dies ends the others and the launcher returns its status (no hang on the survivors' barrier)"""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys; sys.path.insert(0, %r); import bench; "
+            "sys.exit(bench.launch_ranks(2, ['--definitely-not-a-flag'], timeout=120))" % root)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=200)
+    assert r.returncode != 0

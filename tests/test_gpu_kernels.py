@@ -502,7 +502,9 @@ def test_gru_final_state(ops, B, L, D):
     xg = x.cuda().requires_grad_(True)
     out = ops.gru_final_state(xg, mask.cuda(), W["weight_ih_l0"], W["weight_hh_l0"], W["bias_ih_l0"], W["bias_hh_l0"])
     assert relerr(out, h) < FP32_TOL
+    ops.gru_status()                                   # the forward recurrence's grid barrier did not time out
     out.backward(dy.cuda())
+    ops.gru_status()                                   # ... nor the backward's
     assert relerr(xg.grad, xr.grad) < 5e-5
     for k, p_ in rnn.named_parameters():
         assert relerr(W[k].grad, p_.grad) < 5e-5, k
@@ -510,6 +512,43 @@ def test_gru_final_state(ops, B, L, D):
     with torch.no_grad():
         assert torch.equal(ops.gru_final_state(x.cuda(), mask.cuda(), W["weight_ih_l0"], W["weight_hh_l0"], W["bias_ih_l0"],
                                                W["bias_hh_l0"]), out.detach())
+
+
+def test_gru_barrier_timeout_is_loud(ops):
+    """a grid-barrier time-out of the persistent GRU kernels must surface: the workgroups that give up NaN-poison their
+    outputs and nr_gru_status reports it.  The test hook shrinks the spin limit to one poll so the time-out path runs
+    (the kernel still terminates: every barrier has a bounded spin)."""
+    from newsrec_hip import _lib
+    from newsrec_hip._lib import NewsrecError
+    L_ = _lib.load()
+    g = G(5)
+    B, L, D = 32, 50, 300
+    x = torch.randn(B, L, D, generator=g).cuda().requires_grad_(True)
+    mask = torch.ones(B, L, dtype=torch.int64).cuda()
+    rnn = torch.nn.GRU(D, D, batch_first=True)
+    W = {k: v.detach().clone().cuda().requires_grad_(True) for k, v in rnn.state_dict().items()}
+    args = (W["weight_ih_l0"], W["weight_hh_l0"], W["bias_ih_l0"], W["bias_hh_l0"])
+    good = ops.gru_final_state(x, mask, *args)
+    ops.gru_status()
+    assert torch.isfinite(good).all()
+    try:
+        assert L_.nr_gru_debug_set_spin_limit(1) == 0
+        bad = ops.gru_final_state(x, mask, *args)
+        with pytest.raises(NewsrecError, match="timed out"):
+            ops.gru_status()
+        assert torch.isnan(bad).any()                  # the failure reaches the user vector, hence the loss
+        L_.nr_gru_debug_set_spin_limit(0)              # forward healthy again, backward with the tiny limit
+        out = ops.gru_final_state(x, mask, *args)
+        L_.nr_gru_debug_set_spin_limit(1)
+        out.backward(torch.ones_like(out))
+        with pytest.raises(NewsrecError, match="timed out"):
+            ops.gru_status()
+        assert torch.isnan(W["weight_ih_l0"].grad).any()
+    finally:
+        L_.nr_gru_debug_set_spin_limit(0)
+    again = ops.gru_final_state(x, mask, *args)        # default limit restored: healthy and equal to the first result
+    ops.gru_status()
+    assert torch.equal(again, good)
 
 
 # ------------------------------------------------------------------ on-device per-impression metrics (SURVEY §8 f2)
