@@ -185,6 +185,32 @@ int nr_tfm_layer_fwd_f32(const float* x, const int64_t* mask, int64_t N, int64_t
 size_t nr_tfm_layer_bwd_ws_bytes(int64_t N, int64_t S, int64_t D);
 int nr_tfm_layer_bwd_f32(const float* dy, const float* x, const int64_t* mask, int64_t N, int64_t S, int64_t D, int64_t H, const nr_tfm_weights* w, float p_drop, uint64_t seed, uint32_t site_base, int mask_mode, const nr_tfm_saved* saved, nr_tfm_grads* grads, float* dx, void* ws, size_t ws_bytes, void* stream);
 
+/* ---- packed title tokens: the news tower over real token rows only ------------------------------------
+ * The reference pads every title to T tokens (utils/dataset.py:72-100) and runs its encoders over all of them
+ * (models/modules/encoder.py:130-143); at MIND-like title lengths about half the rows of a step are padding.  In the
+ * reference's own arithmetic a padded position of a title with >= 1 real token contributes exact zeros everywhere that
+ * is kept (masked key: exp(x - 1e5 - max) == 0.0f, attention.py:24,49,90; masked query: dropped by the pooling softmax
+ * the same way; gradients carry those zeros), so running the layer on the real rows only gives the same news vectors
+ * and parameter gradients.  Titles with NO real token (news 0, the padding of candidate lists and histories) keep all
+ * T rows: with every key masked the shifted scores still rank.  Dropout keep-bits stay indexed by the ORIGINAL
+ * position (row_map), so train-mode results equal the padded layout's.
+ * nr_pack_plan: offs [N+1] int32 (exclusive scan of len'[n] = len[n] ? len[n] : T), info[0] = total rows R,
+ *   info[1] = 1 iff every mask row is prefix-shaped (mask[n][j] == (j < len[n])) — the caller must use the padded
+ *   entry points when it is 0.  title_keep (may be NULL) [N] 0/1: titles with 0 get NO rows (len' = 0) — for history
+ *   slots the user encoder masks out (his_mask == 0 under TfmUserEncoder / RnnUserEncoder, encoder.py:216-233,314-327):
+ *   their news vectors reach nothing that is kept and receive exactly zero gradient; pooling returns a zero vector
+ *   for them.  nr_pack_ids: ids_packed [R], row_map [R] (packed row -> n*T + j).
+ * The *_packed_* entry points take x / y / saved activations with R rows (allocate nr_tfm_saved for R rows, stats
+ * [4,R]; row_max/row_sum stay [N,H,S]) and need S <= 32, head dim <= 64; workspace: nr_tfm_layer_bwd_ws_bytes(R, 1, D). */
+int nr_pack_plan(const int64_t* mask, const int64_t* title_keep, int64_t N, int64_t T, int32_t* offs, int32_t* info, void* stream);
+int nr_pack_ids(const int64_t* ids, const int32_t* offs, int64_t N, int64_t T, int64_t* ids_packed, int32_t* row_map, void* stream);
+int nr_tfm_layer_packed_fwd_f32(const float* x, const int64_t* mask, const int32_t* offs, const int32_t* row_map, int64_t N, int64_t S, int64_t R, int64_t D, int64_t H, const nr_tfm_weights* w, float p_drop, uint64_t seed, uint32_t site_base, int mask_mode, nr_tfm_saved* saved, float* y, void* stream);
+int nr_tfm_layer_packed_bwd_f32(const float* dy, const float* x, const int64_t* mask, const int32_t* offs, const int32_t* row_map, int64_t N, int64_t S, int64_t R, int64_t D, int64_t H, const nr_tfm_weights* w, float p_drop, uint64_t seed, uint32_t site_base, int mask_mode, const nr_tfm_saved* saved, nr_tfm_grads* grads, float* dx, void* ws, size_t ws_bytes, void* stream);
+/* scaled_dp_attention pooling (attention.py:6-34) over packed key/value [R,D]; prob [nseq,S] gets 0 at dropped positions.
+ * Backward: dkeypre / dvalue [R,D]; ws: nr_query_pool_bwd_ws_bytes(nseq, D). */
+int nr_query_pool_packed_fwd_f32(const float* key, const float* value, const int32_t* offs, int64_t R, const float* query, const int64_t* mask, int64_t nseq, int64_t S, int64_t D, float* out, float* prob, void* stream);
+int nr_query_pool_packed_bwd_f32(const float* key, const float* value, const int32_t* offs, int64_t R, const float* query, const float* prob, const float* dout, int64_t nseq, int64_t S, int64_t D, int tanh_key, float* dkeypre, float* dvalue, float* dquery, void* ws, size_t ws_bytes, void* stream);
+
 /* ---- GRU user encoder — RnnUserEncoder, models/modules/encoder.py:204-233 -----------------------------
  * One-layer nn.GRU(Din, H, batch_first) over x [B,L,Din], packed by len_b = sum_l mask[b,l] (>= 1: the
  * reference sets his_mask[b,0] = 1 for an empty history, dataset.py:140-141); the user vector is the state

@@ -181,12 +181,17 @@ __global__ __launch_bounds__(256) void mhsa_fwd_mfma_kernel(const float* __restr
     const bool active = w < nh;
     const int A = H * dh;
     const int64_t ld = 3 * (int64_t)A;
-    const float* base = qkv + (int64_t)n * S * ld + hd0 * dh;
-    heads_in<DHP>(Qt, base, ld, S, dh, nh, tid, vec);
-    heads_in<DHP>(Kt, base + A, ld, S, dh, nh, tid, vec);
-    heads_in<DHP>(Vt, base + 2 * A, ld, S, dh, nh, tid, vec);
+    // packed layout: this sequence owns rows offs[n] .. offs[n+1] (Sn <= S of them); S stays the ORIGINAL length for
+    // every index that names a position (mask, softmax statistics, dropout counters)
+    const int64_t row0 = dc.offs ? (int64_t)dc.offs[n] : (int64_t)n * S;
+    const int Sn = dc.offs ? dc.offs[n + 1] - dc.offs[n] : S;
+    if (Sn == 0) return;                                        // a title with no rows (block-uniform)
+    const float* base = qkv + row0 * ld + hd0 * dh;
+    heads_in<DHP>(Qt, base, ld, Sn, dh, nh, tid, vec);
+    heads_in<DHP>(Kt, base + A, ld, Sn, dh, nh, tid, vec);
+    heads_in<DHP>(Vt, base + 2 * A, ld, Sn, dh, nh, tid, vec);
     float* Qs = Qt + w * TS; float* Ks = Kt + w * TS; float* Vs = Vt + w * TS;
-    if (active) { tile_zero_pad<DHP>(Qs, S, dh, lane); tile_zero_pad<DHP>(Ks, S, dh, lane); tile_zero_pad<DHP>(Vs, S, dh, lane); }
+    if (active) { tile_zero_pad<DHP>(Qs, Sn, dh, lane); tile_zero_pad<DHP>(Ks, Sn, dh, lane); tile_zero_pad<DHP>(Vs, Sn, dh, lane); }
     __syncthreads();
     f32x16 st;
     if (active) {
@@ -198,7 +203,7 @@ __global__ __launch_bounds__(256) void mhsa_fwd_mfma_kernel(const float* __restr
         for (int r = 0; r < 16; ++r) {
             const int j = krow(r, h);
             float x = st[r] / sq;
-            x += (j < S) ? (mask[(int64_t)n * S + j] ? 0.f : dc.mask_fill) : -INFINITY;
+            x += (j < Sn) ? (mask[(int64_t)n * S + j] ? 0.f : dc.mask_fill) : -INFINITY;
             st[r] = x;
             m = fmaxf(m, x);
         }
@@ -214,7 +219,7 @@ __global__ __launch_bounds__(256) void mhsa_fwd_mfma_kernel(const float* __restr
         sum += __shfl_xor(sum, 32, 64);
         if (sum == 0.f) sum = 1.f;                             // ... and the probabilities are 0, not 0/0
         const int64_t qrow = ((int64_t)n * H + hd) * S + l31;
-        if (row_max && h == 0 && l31 < S) { row_max[qrow] = m; row_sum[qrow] = sum; }
+        if (row_max && h == 0 && l31 < Sn) { row_max[qrow] = m; row_sum[qrow] = sum; }
         unsigned bits = 0xFFFFu;
         float scale = 1.f;
         if (dc.p > 0.f) { bits = keep_bits16(dc, drop_threshold(dc.p), qrow, S, h); scale = 1.0f / (1.0f - dc.p); }
@@ -234,7 +239,7 @@ __global__ __launch_bounds__(256) void mhsa_fwd_mfma_kernel(const float* __restr
         }
     }
     __syncthreads();
-    heads_out<DHP>(ctx + (int64_t)n * S * A + hd0 * dh, A, Qt, S, dh, nh, tid, vec);
+    heads_out<DHP>(ctx + row0 * A + hd0 * dh, A, Qt, Sn, dh, nh, tid, vec);
 }
 
 template <int DHP>
@@ -257,20 +262,23 @@ __global__ __launch_bounds__(256) void mhsa_bwd_mfma_kernel(const float* __restr
     const bool active = w < nh;
     const int A = H * dh;
     const int64_t ld = 3 * (int64_t)A;
-    const float* base = qkv + (int64_t)n * S * ld + hd0 * dh;
-    heads_in<DHP>(Qt, base, ld, S, dh, nh, tid, vec);
-    heads_in<DHP>(Kt, base + A, ld, S, dh, nh, tid, vec);
-    heads_in<DHP>(Vt, base + 2 * A, ld, S, dh, nh, tid, vec);
-    heads_in<DHP>(Gt, dctx + (int64_t)n * S * A + hd0 * dh, A, S, dh, nh, tid, vec);
+    const int64_t row0 = dc.offs ? (int64_t)dc.offs[n] : (int64_t)n * S;       // packed layout: see the forward kernel
+    const int Sn = dc.offs ? dc.offs[n + 1] - dc.offs[n] : S;
+    if (Sn == 0) return;
+    const float* base = qkv + row0 * ld + hd0 * dh;
+    heads_in<DHP>(Qt, base, ld, Sn, dh, nh, tid, vec);
+    heads_in<DHP>(Kt, base + A, ld, Sn, dh, nh, tid, vec);
+    heads_in<DHP>(Vt, base + 2 * A, ld, Sn, dh, nh, tid, vec);
+    heads_in<DHP>(Gt, dctx + row0 * A + hd0 * dh, A, Sn, dh, nh, tid, vec);
     float* Qs = Qt + w * TS; float* Ks = Kt + w * TS; float* Vs = Vt + w * TS; float* Gs = Gt + w * TS;
     float* Ms = St + w * 128; float* Ls = Ms + 32; float* Dsh = Ms + 64; float* Mk = Ms + 96;
     unsigned* Kb = reinterpret_cast<unsigned*>(St + HPG * 128) + w * 32;
     const int64_t qrow0 = ((int64_t)n * H + hd) * S;
     if (active) {
-        tile_zero_pad<DHP>(Qs, S, dh, lane); tile_zero_pad<DHP>(Ks, S, dh, lane);
-        tile_zero_pad<DHP>(Vs, S, dh, lane); tile_zero_pad<DHP>(Gs, S, dh, lane);
+        tile_zero_pad<DHP>(Qs, Sn, dh, lane); tile_zero_pad<DHP>(Ks, Sn, dh, lane);
+        tile_zero_pad<DHP>(Vs, Sn, dh, lane); tile_zero_pad<DHP>(Gs, Sn, dh, lane);
         if (lane < 32) {
-            const bool ok = lane < S;
+            const bool ok = lane < Sn;
             Ms[lane] = ok ? row_max[qrow0 + lane] : 0.f;
             Ls[lane] = ok ? row_sum[qrow0 + lane] : 1.f;
             Mk[lane] = ok ? (mask[(int64_t)n * S + lane] ? 0.f : dc.mask_fill) : -INFINITY;
@@ -332,7 +340,7 @@ __global__ __launch_bounds__(256) void mhsa_bwd_mfma_kernel(const float* __restr
         }
     }
     __syncthreads();                                           // K and V tiles are dead: reuse them as staging
-    float* dbase = dqkv + (int64_t)n * S * ld + hd0 * dh;
+    float* dbase = dqkv + row0 * ld + hd0 * dh;
     if (active) {
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt) {
@@ -342,8 +350,8 @@ __global__ __launch_bounds__(256) void mhsa_bwd_mfma_kernel(const float* __restr
         }
     }
     __syncthreads();
-    heads_out<DHP>(dbase, ld, Kt, S, dh, nh, tid, vec);
-    heads_out<DHP>(dbase + A, ld, Vt, S, dh, nh, tid, vec);
+    heads_out<DHP>(dbase, ld, Kt, Sn, dh, nh, tid, vec);
+    heads_out<DHP>(dbase + A, ld, Vt, Sn, dh, nh, tid, vec);
     __syncthreads();
     if (active) {
 #pragma unroll
@@ -353,7 +361,7 @@ __global__ __launch_bounds__(256) void mhsa_bwd_mfma_kernel(const float* __restr
         }
     }
     __syncthreads();
-    heads_out<DHP>(dbase + 2 * A, ld, Kt, S, dh, nh, tid, vec);
+    heads_out<DHP>(dbase + 2 * A, ld, Kt, Sn, dh, nh, tid, vec);
 }
 
 bool mhsa_mfma_supported(int S, int dh) { return S >= 1 && S <= 32 && dh >= 1 && dh <= 64; }

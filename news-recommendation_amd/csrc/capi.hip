@@ -69,6 +69,7 @@ static inline DropoutCfg DC(float p, uint64_t seed, uint32_t site) {
 static inline DropoutCfg DCA(float p, uint64_t seed, uint32_t site, int mask_mode) {
     DropoutCfg d = DC(p, seed, site); d.mask_fill = mask_mode ? -INFINITY : -1e5f; return d;
 }
+static inline DropoutCfg DCP(DropoutCfg d, const int* offs, const int* row_map) { d.offs = offs; d.row_map = row_map; return d; }
 static inline float* bump(char*& cur, size_t floats) {
     float* p = reinterpret_cast<float*>(cur);
     cur += ((floats * sizeof(float) + 255) / 256) * 256;
@@ -362,6 +363,36 @@ int nr_query_pool_bwd_f32(const float* key, const float* value, const float* que
     return colsum(dq_part, D, nseq, (int)D, dquery, part, s);
 }
 
+int nr_query_pool_packed_fwd_f32(const float* key, const float* value, const int32_t* offs, int64_t rows, const float* query, const int64_t* mask, int64_t nseq, int64_t Sq, int64_t D, float* out, float* prob, void* stream) {
+    NR_CHECK_ARG(nseq >= 0 && Sq > 0 && D > 0 && rows >= 0 && rows <= nseq * Sq, "query_pool_packed_fwd: bad sizes");
+    NR_CHECK_ARG(nseq == 0 || (key && value && offs && query && out), "query_pool_packed_fwd: null pointer");
+    return pool_fwd(key, value, nullptr, nullptr, 0, query, mask, out, prob, nseq, (int)Sq, (int)D, S(stream), offs, rows);
+}
+
+int nr_query_pool_packed_bwd_f32(const float* key, const float* value, const int32_t* offs, int64_t rows, const float* query, const float* prob, const float* dout, int64_t nseq, int64_t Sq, int64_t D, int tanh_key, float* dkeypre, float* dvalue, float* dquery, void* ws, size_t ws_bytes, void* stream) {
+    NR_CHECK_ARG(nseq > 0 && Sq > 0 && D > 0 && rows >= 0 && rows <= nseq * Sq, "query_pool_packed_bwd: bad sizes");
+    NR_CHECK_ARG(key && value && offs && query && prob && dout && dvalue && dquery && dkeypre, "query_pool_packed_bwd: null pointer");
+    if (!ws || ws_bytes < nr_query_pool_bwd_ws_bytes(nseq, D)) { set_error("query_pool_packed_bwd: workspace too small"); return NR_ERR_WORKSPACE; }
+    char* cur = (char*)ws;
+    float* dq_part = bump(cur, (size_t)nseq * D);
+    float* part = bump(cur, (size_t)colsum_chunks(nseq) * D);
+    hipStream_t s = S(stream);
+    if (int rc = pool_bwd(key, value, query, prob, dout, dkeypre, dvalue, dq_part, nseq, (int)Sq, (int)D, tanh_key, 0, s, offs, rows)) return rc;
+    return colsum(dq_part, D, nseq, (int)D, dquery, part, s);
+}
+
+int nr_pack_plan(const int64_t* mask, const int64_t* title_keep, int64_t N, int64_t T, int32_t* offs, int32_t* info, void* stream) {
+    NR_CHECK_ARG(N >= 0 && T > 0 && T <= 1024 && N * T < (int64_t)1 << 31, "pack_plan: bad sizes N=%lld T=%lld", (long long)N, (long long)T);
+    NR_CHECK_ARG(offs && info && (N == 0 || mask), "pack_plan: null pointer");
+    return pack_plan(mask, title_keep, N, (int)T, offs, info, S(stream));
+}
+
+int nr_pack_ids(const int64_t* ids, const int32_t* offs, int64_t N, int64_t T, int64_t* ids_packed, int32_t* row_map, void* stream) {
+    NR_CHECK_ARG(N >= 0 && T > 0, "pack_ids: bad sizes");
+    NR_CHECK_ARG(N == 0 || (ids && offs && ids_packed && row_map), "pack_ids: null pointer");
+    return pack_ids(ids, offs, N, (int)T, ids_packed, row_map, S(stream));
+}
+
 int nr_seq_reduce_f32(const float* x, const float* table, const int64_t* idx, int64_t table_rows, int64_t nseq, int64_t Sq, int64_t D, int mean, float* out, void* stream) {
     NR_CHECK_ARG(nseq >= 0 && Sq > 0 && D > 0, "seq_reduce: bad sizes");
     NR_CHECK_ARG(nseq == 0 || out, "seq_reduce: null pointer");
@@ -450,15 +481,16 @@ static int copy_d2d(void* dst, const void* src, size_t bytes, hipStream_t s) {
     return NR_OK;
 }
 
-int nr_tfm_layer_fwd_f32(const float* x, const int64_t* mask, int64_t N, int64_t Sq, int64_t D, int64_t H, const nr_tfm_weights* w, float p_drop, uint64_t seed, uint32_t site_base, int mask_mode, nr_tfm_saved* sv, float* y, void* stream) {
-    NR_CHECK_ARG(N >= 0 && Sq > 0 && D > 0 && H > 0, "tfm_layer_fwd: bad sizes");
+// one implementation for the dense [N,S,D] layout (offs == NULL, R = N*S) and the packed one (R = offs[N] rows)
+static int tfm_layer_fwd(const float* x, const int64_t* mask, int64_t N, int64_t Sq, int64_t R, int64_t D, int64_t H, const nr_tfm_weights* w,
+                         float p_drop, uint64_t seed, uint32_t site_base, int mask_mode, nr_tfm_saved* sv, float* y,
+                         const int* offs, const int* row_map, hipStream_t s) {
+    NR_CHECK_ARG(N >= 0 && Sq > 0 && D > 0 && H > 0 && R >= 0, "tfm_layer_fwd: bad sizes");
     NR_CHECK_ARG(w && sv && x && mask && y, "tfm_layer_fwd: null pointer");
     NR_CHECK_ARG(D % H == 0, "tfm_layer_fwd: hidden dim %lld not divisible by %lld heads (the reference's dense layers need all_head_size == hidden_dim)", (long long)D, (long long)H);
     NR_CHECK_ARG(sv->qkv && sv->ctx && sv->s1 && sv->y1 && sv->a && sv->s2, "tfm_layer_fwd: missing activation buffer");
     NR_CHECK_ARG(p_drop >= 0.f && p_drop < 1.f, "tfm_layer_fwd: p_drop %f not in [0,1)", p_drop);
-    if (N == 0) return NR_OK;
-    hipStream_t s = S(stream);
-    const int64_t R = N * Sq;
+    if (N == 0 || R == 0) return NR_OK;
     const size_t DD = (size_t)D * D;
     const float* wqkv = w->wq;
     const float* bqkv = w->bq;
@@ -477,12 +509,26 @@ int nr_tfm_layer_fwd_f32(const float* x, const int64_t* mask, int64_t N, int64_t
     float* mean2 = sv->stats ? sv->stats + 2 * R : nullptr;
     float* rstd2 = sv->stats ? sv->stats + 3 * R : nullptr;
     if (int rc = linear_fwd(x, D, wqkv, bqkv, R, D, 3 * D, EPI_NONE, sv->qkv, nullptr, s)) return rc;
-    if (int rc = mhsa_fwd(sv->qkv, mask, sv->ctx, sv->row_max, sv->row_sum, N, (int)Sq, (int)H, (int)(D / H), DCA(p_drop, seed, site_base, mask_mode), s)) return rc;
+    if (int rc = mhsa_fwd(sv->qkv, mask, sv->ctx, sv->row_max, sv->row_sum, N, (int)Sq, (int)H, (int)(D / H),
+                          DCP(DCA(p_drop, seed, site_base, mask_mode), offs, nullptr), s)) return rc;
     if (int rc = linear_fwd(sv->ctx, D, w->wo, w->bo, R, D, D, EPI_NONE, sv->s1, nullptr, s)) return rc;
-    if (int rc = ln_fwd(sv->s1, x, w->ln1_g, w->ln1_b, sv->y1, sv->s1, mean1, rstd1, R, (int)D, 1e-12f, DC(p_drop, seed, site_base + 1), s)) return rc;
+    if (int rc = ln_fwd(sv->s1, x, w->ln1_g, w->ln1_b, sv->y1, sv->s1, mean1, rstd1, R, (int)D, 1e-12f,
+                        DCP(DC(p_drop, seed, site_base + 1), nullptr, row_map), s)) return rc;
     if (int rc = linear_fwd(sv->y1, D, w->w1, w->b1, R, D, 4 * D, EPI_GELU, sv->a, sv->z, s)) return rc;
     if (int rc = linear_fwd(sv->a, 4 * D, w->w2, w->b2, R, 4 * D, D, EPI_NONE, sv->s2, nullptr, s)) return rc;
-    return ln_fwd(sv->s2, sv->y1, w->ln2_g, w->ln2_b, y, sv->s2, mean2, rstd2, R, (int)D, 1e-12f, DC(p_drop, seed, site_base + 2), s);
+    return ln_fwd(sv->s2, sv->y1, w->ln2_g, w->ln2_b, y, sv->s2, mean2, rstd2, R, (int)D, 1e-12f,
+                  DCP(DC(p_drop, seed, site_base + 2), nullptr, row_map), s);
+}
+
+int nr_tfm_layer_fwd_f32(const float* x, const int64_t* mask, int64_t N, int64_t Sq, int64_t D, int64_t H, const nr_tfm_weights* w, float p_drop, uint64_t seed, uint32_t site_base, int mask_mode, nr_tfm_saved* sv, float* y, void* stream) {
+    return tfm_layer_fwd(x, mask, N, Sq, N * Sq, D, H, w, p_drop, seed, site_base, mask_mode, sv, y, nullptr, nullptr, S(stream));
+}
+
+int nr_tfm_layer_packed_fwd_f32(const float* x, const int64_t* mask, const int32_t* offs, const int32_t* row_map, int64_t N, int64_t Sq, int64_t R, int64_t D, int64_t H, const nr_tfm_weights* w, float p_drop, uint64_t seed, uint32_t site_base, int mask_mode, nr_tfm_saved* sv, float* y, void* stream) {
+    NR_CHECK_ARG(offs && row_map, "tfm_layer_packed_fwd: null offsets / row map");
+    NR_CHECK_ARG(R <= N * Sq, "tfm_layer_packed_fwd: %lld packed rows exceed N*S = %lld", (long long)R, (long long)(N * Sq));
+    NR_UNSUPPORTED(!mhsa_mfma_supported((int)Sq, (int)(H > 0 ? D / H : 0)), "tfm_layer_packed_fwd: packed sequences need S <= 32 and head dim <= 64");
+    return tfm_layer_fwd(x, mask, N, Sq, R, D, H, w, p_drop, seed, site_base, mask_mode, sv, y, offs, row_map, S(stream));
 }
 
 size_t nr_tfm_layer_bwd_ws_bytes(int64_t N, int64_t Sq, int64_t D) {
@@ -500,13 +546,11 @@ size_t nr_tfm_layer_bwd_ws_bytes(int64_t N, int64_t Sq, int64_t D) {
     return b + wmax;
 }
 
-int nr_tfm_layer_bwd_f32(const float* dy, const float* x, const int64_t* mask, int64_t N, int64_t Sq, int64_t D, int64_t H, const nr_tfm_weights* w, float p_drop, uint64_t seed, uint32_t site_base, int mask_mode, const nr_tfm_saved* sv, nr_tfm_grads* g, float* dx, void* ws, size_t ws_bytes, void* stream) {
-    NR_CHECK_ARG(N > 0 && Sq > 0 && D > 0 && H > 0 && D % H == 0, "tfm_layer_bwd: bad sizes");
+static int tfm_layer_bwd(const float* dy, const float* x, const int64_t* mask, int64_t N, int64_t Sq, int64_t R, int64_t D, int64_t H, const nr_tfm_weights* w, float p_drop, uint64_t seed, uint32_t site_base, int mask_mode, const nr_tfm_saved* sv, nr_tfm_grads* g, float* dx, void* ws, size_t ws_bytes, const int* offs, const int* row_map, hipStream_t s) {
+    NR_CHECK_ARG(N > 0 && Sq > 0 && D > 0 && H > 0 && D % H == 0 && R > 0, "tfm_layer_bwd: bad sizes");
     NR_CHECK_ARG(dy && x && mask && w && sv && g && dx, "tfm_layer_bwd: null pointer");
     NR_CHECK_ARG(sv->qkv && sv->ctx && sv->s1 && sv->y1 && sv->z && sv->a && sv->s2 && sv->stats && sv->row_max && sv->row_sum, "tfm_layer_bwd: missing saved activation");
-    if (!ws || ws_bytes < nr_tfm_layer_bwd_ws_bytes(N, Sq, D)) { set_error("tfm_layer_bwd: workspace too small"); return NR_ERR_WORKSPACE; }
-    hipStream_t s = S(stream);
-    const int64_t R = N * Sq;
+    if (!ws || ws_bytes < nr_tfm_layer_bwd_ws_bytes(R, 1, D)) { set_error("tfm_layer_bwd: workspace too small"); return NR_ERR_WORKSPACE; }
     const size_t DD = (size_t)D * D;
     char* cur = (char*)ws;
     float* ds2 = bump(cur, (size_t)R * D);
@@ -527,7 +571,7 @@ int nr_tfm_layer_bwd_f32(const float* dy, const float* x, const int64_t* mask, i
     NR_CHECK_ARG(wqkv, "tfm_layer_bwd: q/k/v weights are not contiguous and no packed copy saved");
 
     // LN2 <- dy
-    if (int rc = layernorm_bwd(dy, sv->s2, mean2, rstd2, w->ln2_g, R, (int)D, DC(p_drop, seed, site_base + 2), ds2,
+    if (int rc = layernorm_bwd(dy, sv->s2, mean2, rstd2, w->ln2_g, R, (int)D, DCP(DC(p_drop, seed, site_base + 2), nullptr, row_map), ds2,
                                p_drop > 0.f ? dh2 : nullptr, g->dln2_g, g->dln2_b, lnws, s)) return rc;
     // FFN2: dW2 = dh2^T a ; dz = (dh2 W2) * gelu'(z)
     if (int rc = linear_bwd_weight(dh2, D, sv->a, 4 * D, R, D, 4 * D, g->dw2, g->db2, wws, wws_bytes, 0, 0, s)) return rc;
@@ -536,14 +580,14 @@ int nr_tfm_layer_bwd_f32(const float* dy, const float* x, const int64_t* mask, i
     if (int rc = linear_bwd_weight(dz, 4 * D, sv->y1, D, R, 4 * D, D, g->dw1, g->db1, wws, wws_bytes, 0, 0, s)) return rc;
     if (int rc = linear_bwd_input(dz, 4 * D, w->w1, R, 4 * D, D, EPI_ADD_AUX, ds2, nullptr, dy1, s)) return rc;
     // LN1
-    if (int rc = layernorm_bwd(dy1, sv->s1, mean1, rstd1, w->ln1_g, R, (int)D, DC(p_drop, seed, site_base + 1), ds1,
+    if (int rc = layernorm_bwd(dy1, sv->s1, mean1, rstd1, w->ln1_g, R, (int)D, DCP(DC(p_drop, seed, site_base + 1), nullptr, row_map), ds1,
                                p_drop > 0.f ? dh1 : nullptr, g->dln1_g, g->dln1_b, lnws, s)) return rc;
     // attention output projection
     if (int rc = linear_bwd_weight(dh1, D, sv->ctx, D, R, D, D, g->dwo, g->dbo, wws, wws_bytes, 0, 0, s)) return rc;
     if (int rc = linear_bwd_input(dh1, D, w->wo, R, D, D, EPI_NONE, nullptr, nullptr, dctx, s)) return rc;
     // attention core
     if (int rc = mhsa_bwd(sv->qkv, mask, sv->ctx, dctx, sv->row_max, sv->row_sum, dqkv, N, (int)Sq, (int)H, (int)(D / H),
-                          DCA(p_drop, seed, site_base, mask_mode), s)) return rc;
+                          DCP(DCA(p_drop, seed, site_base, mask_mode), offs, nullptr), s)) return rc;
     // QKV projection: packed dW [3D, D], db [3D]; dx = dqkv Wqkv + ds1 (residual)
     const bool gcontig = contiguous3(g->dwq, g->dwk, g->dwv, DD) && contiguous3(g->dbq, g->dbk, g->dbv, (size_t)D);
     float* dwp = gcontig ? g->dwq : dwqkv;
@@ -558,6 +602,17 @@ int nr_tfm_layer_bwd_f32(const float* dy, const float* x, const int64_t* mask, i
         }
     }
     return linear_bwd_input(dqkv, 3 * D, wqkv, R, 3 * D, D, EPI_ADD_AUX, ds1, nullptr, dx, s);
+}
+
+int nr_tfm_layer_bwd_f32(const float* dy, const float* x, const int64_t* mask, int64_t N, int64_t Sq, int64_t D, int64_t H, const nr_tfm_weights* w, float p_drop, uint64_t seed, uint32_t site_base, int mask_mode, const nr_tfm_saved* sv, nr_tfm_grads* g, float* dx, void* ws, size_t ws_bytes, void* stream) {
+    return tfm_layer_bwd(dy, x, mask, N, Sq, N * Sq, D, H, w, p_drop, seed, site_base, mask_mode, sv, g, dx, ws, ws_bytes, nullptr, nullptr, S(stream));
+}
+
+int nr_tfm_layer_packed_bwd_f32(const float* dy, const float* x, const int64_t* mask, const int32_t* offs, const int32_t* row_map, int64_t N, int64_t Sq, int64_t R, int64_t D, int64_t H, const nr_tfm_weights* w, float p_drop, uint64_t seed, uint32_t site_base, int mask_mode, const nr_tfm_saved* sv, nr_tfm_grads* g, float* dx, void* ws, size_t ws_bytes, void* stream) {
+    NR_CHECK_ARG(offs && row_map, "tfm_layer_packed_bwd: null offsets / row map");
+    NR_CHECK_ARG(R <= N * Sq, "tfm_layer_packed_bwd: %lld packed rows exceed N*S = %lld", (long long)R, (long long)(N * Sq));
+    NR_UNSUPPORTED(!mhsa_mfma_supported((int)Sq, (int)(H > 0 ? D / H : 0)), "tfm_layer_packed_bwd: packed sequences need S <= 32 and head dim <= 64");
+    return tfm_layer_bwd(dy, x, mask, N, Sq, R, D, H, w, p_drop, seed, site_base, mask_mode, sv, g, dx, ws, ws_bytes, offs, row_map, S(stream));
 }
 
 // ------------------------------------------------------------------------------------ GRU user encoder

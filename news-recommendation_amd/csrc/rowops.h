@@ -14,6 +14,10 @@ struct DropoutCfg {
     // -INFINITY = HF BertModel under torch SDPA (masked keys excluded, a sequence with no valid key gets zero
     // probabilities = zero context: torch's safe softmax)
     float mask_fill = -1e5f;
+    // packed title tokens (rows of padded positions removed, see nr_pack_plan): dropout keep-bits stay indexed by the
+    // ORIGINAL position, so results equal the padded layout's.
+    const int* row_map = nullptr;   // LayerNorm kernels: packed row -> original row (n*S + i); NULL = identity
+    const int* offs = nullptr;      // attention kernels: sequence n owns packed rows offs[n] .. offs[n+1]; NULL = dense [N,S]
 };
 
 int gather_rows(const float* table, int64_t V, int E, const int64_t* ids, int64_t n, float* out, int* oob_flag, hipStream_t s);
@@ -25,6 +29,8 @@ int ln_bwd_blocks(int64_t R);
 int ln_bwd(const float* dy, const float* sin, const float* mean, const float* rstd, const float* gamma, float* ds,
            float* dh, float* dgamma_part, float* dbeta_part, int64_t R, int D, DropoutCfg dc, hipStream_t s);
 int colsum_chunks(int64_t R);
+int pack_plan(const int64_t* mask, const int64_t* title_keep, int64_t N, int T, int* offs, int* info, hipStream_t s);
+int pack_ids(const int64_t* ids, const int* offs, int64_t N, int T, int64_t* ids_packed, int* row_map, hipStream_t s);
 int colsum(const float* in, int64_t ld, int64_t R, int N, float* out, float* part, hipStream_t s);
 int conv_pack(const float* w, float* wf, float* wb, int D, int E, hipStream_t s);
 int conv_unpack_grad(const float* gwf, float* gw, int D, int E, hipStream_t s);

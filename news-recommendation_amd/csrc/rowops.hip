@@ -109,7 +109,8 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ h
     const int64_t row = (int64_t)blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6);
     if (row >= R) return;
     const float* hr = h + row * D;
-    const float* xr = x ? x + (x_period > 0 ? row % x_period : row) * D : nullptr;
+    const int64_t prow = dc.row_map ? (int64_t)dc.row_map[row] : row;       // Philox element index: the ORIGINAL row
+    const float* xr = x ? x + (x_period > 0 ? prow % x_period : row) * D : nullptr;
     float v[IT][VEC];
     const uint32_t thr = drop_threshold(dc.p);
     const float scale = dc.p > 0.f ? 1.0f / (1.0f - dc.p) : 1.0f;
@@ -125,11 +126,11 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ h
             } else t[0] = hr[c];
             if (dc.p > 0.f) {
                 if (VEC == 4) {
-                    const Philox4 rn = philox4x32_10(dc.seed, (uint64_t)(row * D + c) >> 2, dc.site);
+                    const Philox4 rn = philox4x32_10(dc.seed, (uint64_t)(prow * D + c) >> 2, dc.site);
 #pragma unroll
                     for (int e = 0; e < VEC; ++e) t[e] = philox_pick(rn, e) >= thr ? t[e] * scale : 0.f;
                 } else {
-                    const uint64_t idx = (uint64_t)(row * D + c);
+                    const uint64_t idx = (uint64_t)(prow * D + c);
                     const Philox4 rn = philox4x32_10(dc.seed, idx >> 2, dc.site);
                     t[0] = philox_pick(rn, (int)(idx & 3)) >= thr ? t[0] * scale : 0.f;
                 }
@@ -227,6 +228,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
     const float scale = dc.p > 0.f ? 1.0f / (1.0f - dc.p) : 1.0f;
     for (int64_t row = (int64_t)blockIdx.x * WAVES_PER_BLOCK + wid; row < R; row += (int64_t)gridDim.x * WAVES_PER_BLOCK) {
         const float mean = mean_in[row], rstd = rstd_in[row];
+        const int64_t prow = dc.row_map ? (int64_t)dc.row_map[row] : row;
         float g[IT][VEC], xh[IT][VEC];
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
@@ -264,11 +266,11 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
                 for (int e = 0; e < VEC; ++e) { o[e] = rstd * (g[it][e] - c1 - xh[it][e] * c2); od[e] = o[e]; }
                 if (dh && dc.p > 0.f) {
                     if (VEC == 4) {
-                        const Philox4 rn = philox4x32_10(dc.seed, (uint64_t)(row * D + c) >> 2, dc.site);
+                        const Philox4 rn = philox4x32_10(dc.seed, (uint64_t)(prow * D + c) >> 2, dc.site);
 #pragma unroll
                         for (int e = 0; e < VEC; ++e) od[e] = philox_pick(rn, e) >= thr ? o[e] * scale : 0.f;
                     } else {
-                        const uint64_t idx = (uint64_t)(row * D + c);
+                        const uint64_t idx = (uint64_t)(prow * D + c);
                         const Philox4 rn = philox4x32_10(dc.seed, idx >> 2, dc.site);
                         od[0] = philox_pick(rn, (int)(idx & 3)) >= thr ? o[0] * scale : 0.f;
                     }
@@ -402,6 +404,77 @@ int colsum(const float* in, int64_t ld, int64_t R, int N, float* out, float* par
     else            NR_COLSUM(1, dim3(ctiles, 1), part, (int64_t)N, out, (int64_t)nchunk, (int64_t)nchunk);
 #undef NR_COLSUM
     return check_launch("colsum");
+}
+
+// ------------------------------------------------------------------ packed title tokens
+// The synthetic / MIND title tensors pad every title to T tokens; about half of the rows of a training step are
+// padding.  A padded position of a title with at least one real token never reaches anything that is kept (as a key
+// its softmax weight is exp(x - 1e5 - max) = 0 exactly; as a query its row is dropped by the pooling softmax the same
+// way; its gradients carry those exact zeros), so the news tower can run on the real rows only.  Titles with NO real
+// token (news 0: the padding of candidate lists and histories) keep all T rows: with every key masked the shifted
+// scores still rank.  Plan: len'[n] = len[n] > 0 ? len[n] : T, offs = exclusive scan; info[0] = total rows,
+// info[1] = 1 iff every mask row is prefix-shaped (mask[n][j] == (j < len[n])), the only form the packing is exact for.
+// title_keep (optional, [N] 0/1): titles the caller proves dead (history slots the user encoder masks out: their news
+// vectors never reach the loss and receive exactly zero gradient) get NO rows at all.
+__global__ __launch_bounds__(1024) void pack_plan_kernel(const int64_t* __restrict__ mask, const int64_t* __restrict__ title_keep,
+                                                         int64_t N, int T, int* __restrict__ offs, int* __restrict__ info) {
+    __shared__ int wsum[16];
+    __shared__ int carry;
+    __shared__ int ok_all;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    if (tid == 0) { carry = 0; ok_all = 1; }
+    __syncthreads();
+    for (int64_t base = 0; base < N; base += 1024) {
+        const int64_t n = base + tid;
+        int len = 0, ok = 1;
+        if (n < N) {
+            const int64_t* m = mask + n * T;
+            for (int j = 0; j < T; ++j) len += m[j] != 0;
+            for (int j = 0; j < T; ++j) ok &= ((m[j] != 0) == (j < len));
+            if (len == 0) len = T;
+            if (title_keep && title_keep[n] == 0) len = 0;
+        }
+        if (!ok) ok_all = 0;                              // benign race: every writer stores 0
+        // inclusive scan of len over the 1024 threads: wave scan, then the 16 wave totals
+        int v = len;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int t = __shfl_up(v, o, 64);
+            if (lane >= o) v += t;
+        }
+        if (lane == 63) wsum[w] = v;
+        __syncthreads();
+        int pre = carry;
+        for (int k = 0; k < w; ++k) pre += wsum[k];
+        if (n < N) offs[n] = pre + v - len;               // exclusive
+        __syncthreads();
+        if (tid == 1023) carry = pre + v;
+        __syncthreads();
+    }
+    if (tid == 0) { offs[N] = carry; info[0] = carry; info[1] = ok_all; }
+}
+
+// one wave per title: packed ids and the packed-row -> original-row map
+__global__ __launch_bounds__(256) void pack_ids_kernel(const int64_t* __restrict__ ids, const int* __restrict__ offs, int64_t N, int T,
+                                                       int64_t* __restrict__ ids_packed, int* __restrict__ row_map) {
+    const int lane = threadIdx.x & 63;
+    const int64_t n = (int64_t)blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6);
+    if (n >= N) return;
+    const int o = offs[n], len = offs[n + 1] - o;
+    for (int j = lane; j < len; j += 64) {
+        ids_packed[o + j] = ids[n * T + j];
+        row_map[o + j] = (int)(n * T + j);
+    }
+}
+
+int pack_plan(const int64_t* mask, const int64_t* title_keep, int64_t N, int T, int* offs, int* info, hipStream_t s) {
+    hipLaunchKernelGGL(pack_plan_kernel, dim3(1), dim3(1024), 0, s, mask, title_keep, N, T, offs, info);
+    return check_launch("pack_plan");
+}
+int pack_ids(const int64_t* ids, const int* offs, int64_t N, int T, int64_t* ids_packed, int* row_map, hipStream_t s) {
+    if (N == 0) return NR_OK;
+    hipLaunchKernelGGL(pack_ids_kernel, dim3(cdiv(N, WAVES_PER_BLOCK)), dim3(256), 0, s, ids, offs, N, T, ids_packed, row_map);
+    return check_launch("pack_ids");
 }
 
 // ------------------------------------------------------------------ small elementwise helpers

@@ -19,9 +19,11 @@ int mhsa_bwd_mfma(const float* qkv, const int64_t* mask, const float* dctx, cons
                   float* dqkv, int64_t N, int S, int H, int dh, DropoutCfg dc, hipStream_t s);
 
 int pool_fwd(const float* key, const float* value, const float* table, const int64_t* idx, int64_t nrows, const float* query,
-             const int64_t* mask, float* out, float* prob, int64_t nseq, int S, int D, hipStream_t s);
+             const int64_t* mask, float* out, float* prob, int64_t nseq, int S, int D, hipStream_t s,
+             const int* offs = nullptr, int64_t rows = 0);       // offs: packed sequences (rows = their total)
 int pool_bwd(const float* key, const float* value, const float* query, const float* prob, const float* dout, float* dkeypre,
-             float* dvalue, float* dq_part, int64_t nseq, int S, int D, int tanh_key, int key_is_value, hipStream_t s);
+             float* dvalue, float* dq_part, int64_t nseq, int S, int D, int tanh_key, int key_is_value, hipStream_t s,
+             const int* offs = nullptr, int64_t rows = 0);
 int score_fwd(const float* cdd, const float* table, const int64_t* idx, int64_t nrows, const float* user, const int64_t* label,
               float* logits, float* loss_b, int64_t B, int C, int D, hipStream_t s);
 int score_bwd(const float* cdd, const float* user, const int64_t* label, const float* logits, const float* grad_out,

@@ -75,25 +75,35 @@ __global__ __launch_bounds__(256) void pool_fwd_kernel(const float* __restrict__
                                                        int64_t nrows,
                                                        const float* __restrict__ query, const int64_t* __restrict__ mask,
                                                        float* __restrict__ out, float* __restrict__ prob, int64_t nseq,
-                                                       int S, int D) {
+                                                       int S, int D, const int* __restrict__ offs) {
     __shared__ float sc[64 * SL];
     __shared__ __attribute__((aligned(16))) float part[WPB][IT * 256];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int64_t n = blockIdx.x;
+    // packed layout (offs != NULL, dense key/value only): sequence n owns rows offs[n] .. offs[n+1]; S stays the original
+    // length for the mask / prob indices.  The dropped positions had probability exactly 0 in the padded layout.
+    const int Sn = offs ? offs[n + 1] - offs[n] : S;
+    const int64_t rb = offs ? (int64_t)offs[n] - n * S : 0;       // dense row of (n, s) = n*S + s + rb
+    key += rb * D; value += rb * D;
+    if (Sn == 0) {                                                // a title with no rows: zero vector, zero probabilities
+        for (int c = threadIdx.x; c < D; c += 256) out[n * (int64_t)D + c] = 0.f;
+        if (prob) for (int c = threadIdx.x; c < S; c += 256) prob[n * S + c] = 0.f;
+        return;
+    }
     float4 q[IT];
     load_row<IT>(q, query, D, lane);
     const float sq = sqrtf((float)D);
-    for (int s0 = w; s0 < S; s0 += WPB * PB) {
+    for (int s0 = w; s0 < Sn; s0 += WPB * PB) {
         float4 k[PB][IT];
 #pragma unroll
         for (int b = 0; b < PB; ++b) {
             const int s = s0 + b * WPB;
-            if (s < S) load_row<IT>(k[b], row_ptr(key, table, idx, nrows, n, S, s, D), D, lane);
+            if (s < Sn) load_row<IT>(k[b], row_ptr(key, table, idx, nrows, n, S, s, D), D, lane);
         }
 #pragma unroll
         for (int b = 0; b < PB; ++b) {
             const int s = s0 + b * WPB;
-            if (s < S) {
+            if (s < Sn) {
                 float x = dot_rows<IT>(q, k[b]) / sq;
                 if (mask) x += mask[n * S + s] ? 0.f : MASK_FILL;
                 if (lane == 0) sc[s] = x;
@@ -102,11 +112,11 @@ __global__ __launch_bounds__(256) void pool_fwd_kernel(const float* __restrict__
     }
     __syncthreads();
     // positions lane (and lane + 64 when SL == 2) of the softmax live in this lane
-    const float myscore = lane < S ? sc[lane] : -INFINITY;
-    const float myscore2 = (SL == 2 && lane + 64 < S) ? sc[(SL - 1) * 64 + lane] : -INFINITY;
+    const float myscore = lane < Sn ? sc[lane] : -INFINITY;
+    const float myscore2 = (SL == 2 && lane + 64 < Sn) ? sc[(SL - 1) * 64 + lane] : -INFINITY;
     const float m = wave_max(SL == 2 ? fmaxf(myscore, myscore2) : myscore);
-    const float e = lane < S ? expf(myscore - m) : 0.f;
-    const float e2 = (SL == 2 && lane + 64 < S) ? expf(myscore2 - m) : 0.f;
+    const float e = lane < Sn ? expf(myscore - m) : 0.f;
+    const float e2 = (SL == 2 && lane + 64 < Sn) ? expf(myscore2 - m) : 0.f;
     const float sum = wave_sum(SL == 2 ? e + e2 : e);
     const float p = e / sum, p2 = e2 / sum;
     if (prob && w == 0 && lane < S) prob[n * S + lane] = p;
@@ -114,17 +124,17 @@ __global__ __launch_bounds__(256) void pool_fwd_kernel(const float* __restrict__
     float4 acc[IT];
 #pragma unroll
     for (int it = 0; it < IT; ++it) acc[it] = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int s0 = w; s0 < S; s0 += WPB * PB) {
+    for (int s0 = w; s0 < Sn; s0 += WPB * PB) {
         float4 v[PB][IT];
 #pragma unroll
         for (int b = 0; b < PB; ++b) {
             const int s = s0 + b * WPB;
-            if (s < S) load_row<IT>(v[b], row_ptr(value, table, idx, nrows, n, S, s, D), D, lane);
+            if (s < Sn) load_row<IT>(v[b], row_ptr(value, table, idx, nrows, n, S, s, D), D, lane);
         }
 #pragma unroll
         for (int b = 0; b < PB; ++b) {
             const int s = s0 + b * WPB;
-            if (s < S) axpy_rows<IT>(acc, __shfl((SL == 2 && s >= 64) ? p2 : p, s & 63, 64), v[b]);
+            if (s < Sn) axpy_rows<IT>(acc, __shfl((SL == 2 && s >= 64) ? p2 : p, s & 63, 64), v[b]);
         }
     }
     // fixed-order cross-wave sum (deterministic): wave w writes its partial, the block adds 0+1+2+3
@@ -154,52 +164,61 @@ __global__ __launch_bounds__(256) void pool_bwd_kernel(const float* __restrict__
                                                        const float* __restrict__ query, const float* __restrict__ prob,
                                                        const float* __restrict__ dout, float* __restrict__ dkeypre,
                                                        float* __restrict__ dvalue, float* __restrict__ dq_part,
-                                                       int64_t nseq, int S, int D, int tanh_key, int key_is_value) {
+                                                       int64_t nseq, int S, int D, int tanh_key, int key_is_value,
+                                                       const int* __restrict__ offs) {
     __shared__ float sdp[64 * SL];
     __shared__ __attribute__((aligned(16))) float part[WPB][IT * 256];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int64_t n = blockIdx.x;
+    const int Sn = offs ? offs[n + 1] - offs[n] : S;              // packed layout: see pool_fwd_kernel
+    const int64_t rb = offs ? (int64_t)offs[n] - n * S : 0;
+    key += rb * D; value += rb * D; dvalue += rb * D;
+    if (dkeypre) dkeypre += rb * D;
+    if (Sn == 0) {
+        for (int c = threadIdx.x; c < D; c += 256) dq_part[n * (int64_t)D + c] = 0.f;
+        return;
+    }
     float4 q[IT], g[IT];
     load_row<IT>(q, query, D, lane);
     load_row<IT>(g, dout + n * (int64_t)D, D, lane);
     const float sq = sqrtf((float)D);
-    const float p = lane < S ? prob[n * S + lane] : 0.f;
-    const float p2 = (SL == 2 && lane + 64 < S) ? prob[n * S + lane + 64] : 0.f;
-    for (int s0 = w; s0 < S; s0 += WPB * PB) {
+    const float p = lane < Sn ? prob[n * S + lane] : 0.f;
+    const float p2 = (SL == 2 && lane + 64 < Sn) ? prob[n * S + lane + 64] : 0.f;
+    for (int s0 = w; s0 < Sn; s0 += WPB * PB) {
         float4 v[PB][IT];
 #pragma unroll
         for (int b = 0; b < PB; ++b) {
             const int s = s0 + b * WPB;
-            if (s < S) load_row<IT>(v[b], value + (n * S + s) * (int64_t)D, D, lane);
+            if (s < Sn) load_row<IT>(v[b], value + (n * S + s) * (int64_t)D, D, lane);
         }
 #pragma unroll
         for (int b = 0; b < PB; ++b) {
             const int s = s0 + b * WPB;
-            if (s < S) {
+            if (s < Sn) {
                 const float dp = dot_rows<IT>(g, v[b]);
                 if (lane == 0) sdp[s] = dp;
             }
         }
     }
     __syncthreads();
-    const float mydp = lane < S ? sdp[lane] : 0.f;
-    const float mydp2 = (SL == 2 && lane + 64 < S) ? sdp[(SL - 1) * 64 + lane] : 0.f;
+    const float mydp = lane < Sn ? sdp[lane] : 0.f;
+    const float mydp2 = (SL == 2 && lane + 64 < Sn) ? sdp[(SL - 1) * 64 + lane] : 0.f;
     const float tot = wave_sum(SL == 2 ? p * mydp + p2 * mydp2 : p * mydp);
     const float dscore = p * (mydp - tot) / sq, dscore2 = p2 * (mydp2 - tot) / sq;
     float4 dq[IT];
 #pragma unroll
     for (int it = 0; it < IT; ++it) dq[it] = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int s0 = w; s0 < S; s0 += WPB * PB) {
+    for (int s0 = w; s0 < Sn; s0 += WPB * PB) {
         float4 k[PB][IT];
 #pragma unroll
         for (int b = 0; b < PB; ++b) {
             const int s = s0 + b * WPB;
-            if (s < S) load_row<IT>(k[b], key + (n * S + s) * (int64_t)D, D, lane);
+            if (s < Sn) load_row<IT>(k[b], key + (n * S + s) * (int64_t)D, D, lane);
         }
 #pragma unroll
         for (int b = 0; b < PB; ++b) {
             const int s = s0 + b * WPB;
-            if (s >= S) continue;
+            if (s >= Sn) continue;
             const float ps = __shfl((SL == 2 && s >= 64) ? p2 : p, s & 63, 64);
             const float dsc = __shfl((SL == 2 && s >= 64) ? dscore2 : dscore, s & 63, 64);
             float4 dv[IT], dk[IT];
@@ -375,22 +394,24 @@ static int check_seq_dims(const char* what, int S, int D, int smax = 64) {
 }
 
 int pool_fwd(const float* key, const float* value, const float* table, const int64_t* idx, int64_t nrows, const float* query,
-             const int64_t* mask, float* out, float* prob, int64_t nseq, int S, int D, hipStream_t s) {
+             const int64_t* mask, float* out, float* prob, int64_t nseq, int S, int D, hipStream_t s, const int* offs, int64_t rows) {
     if (nseq == 0) return NR_OK;
     if (int rc = check_seq_dims("pooling", S, D, 128)) return rc;
-    ProfScope prof(FAM_POOL, s, (double)nseq * (2.0 * S * D * 4 + D * 4));
+    NR_UNSUPPORTED(offs && idx, "pooling: packed sequences and table gather are exclusive");
+    ProfScope prof(FAM_POOL, s, (double)(offs ? rows : nseq * S) * (2.0 * D * 4) + (double)nseq * D * 4);
     const dim3 grid((unsigned)nseq);
-    NR_POOL_DISPATCH(pool_fwd_kernel, grid, key, value, table, idx, nrows, query, mask, out, prob, nseq, S, D);
+    NR_POOL_DISPATCH(pool_fwd_kernel, grid, key, value, table, idx, nrows, query, mask, out, prob, nseq, S, D, offs);
     return check_launch("pool_fwd");
 }
 
 int pool_bwd(const float* key, const float* value, const float* query, const float* prob, const float* dout, float* dkeypre,
-             float* dvalue, float* dq_part, int64_t nseq, int S, int D, int tanh_key, int key_is_value, hipStream_t s) {
+             float* dvalue, float* dq_part, int64_t nseq, int S, int D, int tanh_key, int key_is_value, hipStream_t s,
+             const int* offs, int64_t rows) {
     if (nseq == 0) return NR_OK;
     if (int rc = check_seq_dims("pooling bwd", S, D, 128)) return rc;
-    ProfScope prof(FAM_POOL, s, (double)nseq * (4.0 * S * D * 4));
+    ProfScope prof(FAM_POOL, s, (double)(offs ? rows : nseq * S) * (4.0 * D * 4));
     const dim3 grid((unsigned)nseq);
-    NR_POOL_DISPATCH(pool_bwd_kernel, grid, key, value, query, prob, dout, dkeypre, dvalue, dq_part, nseq, S, D, tanh_key, key_is_value);
+    NR_POOL_DISPATCH(pool_bwd_kernel, grid, key, value, query, prob, dout, dkeypre, dvalue, dq_part, nseq, S, D, tanh_key, key_is_value, offs);
     return check_launch("pool_bwd");
 }
 

@@ -154,6 +154,16 @@ class TwoTowerBaseModel(BaseModel):
         idx = x[key + "_idx"].to(self.device)
         return ops.gather_rows_i64(self._news_token_ids, idx), ops.gather_rows_i64(self._news_attn_masks, idx)
 
+    def _news_vectors(self, token_id, attn_mask, title_keep=None):
+        """news vectors only: encoders that offer `news_vectors` skip the padded token rows, and the titles
+        `title_keep` marks 0 (same results wherever they are used)"""
+        fn = getattr(self.newsEncoder, "news_vectors", None)
+        return fn(token_id, attn_mask, title_keep) if fn is not None else self.newsEncoder(token_id, attn_mask)[1]
+
+    def _corpus_vectors(self, x):
+        """news vectors of one chunk of the corpus (encode_news); token embeddings are not needed there"""
+        return self._news_vectors(*self._tokens(x, "cdd"))
+
     def _encode_news(self, x, cdd=True):
         token_id, attn_mask = self._tokens(x, "cdd" if cdd else "his")
         return self.newsEncoder(token_id, attn_mask)
@@ -177,9 +187,15 @@ class TwoTowerBaseModel(BaseModel):
         else:                               # indices only: one gather for candidates + history
             C = x["cdd_idx"].shape[1]
             ids, masks = self._tokens({"all_idx": torch.cat([x["cdd_idx"], x["his_idx"]], dim=1)}, "all")
-        _, news = self.newsEncoder(ids, masks)
+        his_mask = x["his_mask"].to(self.device)
+        keep = None
+        if hasattr(self.userEncoder, "history_keep"):
+            # history slots the user encoder masks out cannot reach the loss: as masked keys / skipped GRU steps their
+            # weight is exactly 0 and so is every gradient into them -> those titles are not encoded at all
+            keep = torch.cat([torch.ones_like(his_mask[:, :1]).expand(-1, C), self.userEncoder.history_keep(his_mask)], dim=1)
+        news = self._news_vectors(ids, masks, keep)
         cdd_news_embedding = news[:, :C]
-        user_embedding = self.userEncoder(news[:, C:], his_mask=x["his_mask"].to(self.device))
+        user_embedding = self.userEncoder(news[:, C:], his_mask=his_mask)
         labels = x["label"].to(self.device)
         loss, _ = ops.score_cross_entropy(cdd_news_embedding, user_embedding, labels)
         return loss
@@ -244,8 +260,7 @@ class TwoTowerBaseModel(BaseModel):
                 x = {"cdd_token_id": tok[s:e], "cdd_attn_mask": self._corpus_attn_masks[s:e]}
             else:
                 x = {"cdd_token_id": torch.from_numpy(ds.token_ids[s:e]), "cdd_attn_mask": torch.from_numpy(ds.attn_masks[s:e])}
-            _, emb = self._encode_news(x)
-            local[s - lo:e - lo] = emb
+            local[s - lo:e - lo] = self._corpus_vectors(x)
         if manager.distributed:
             cap = max(round(per * (r + 1)) - round(per * r) for r in range(ws))
             pad = torch.zeros((cap, self.hidden_dim), dtype=torch.float32, device=self.device)

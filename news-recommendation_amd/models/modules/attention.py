@@ -113,9 +113,11 @@ class TFMLayer(nn.Module):
                     ln1_g=a.output.LayerNorm.weight, ln1_b=a.output.LayerNorm.bias, w1=i.dense.weight, b1=i.dense.bias,
                     w2=o.dense.weight, b2=o.dense.bias, ln2_g=o.LayerNorm.weight, ln2_b=o.LayerNorm.bias)
 
-    def forward(self, hidden_states, attention_mask=None):
+    def forward(self, hidden_states, attention_mask=None, plan=None):
+        """plan (extension): a newsrec_hip.ops.PackPlan -> hidden_states is the packed [rows, D] matrix"""
         if attention_mask is None:
             attention_mask = torch.ones(hidden_states.shape[:2], dtype=torch.int64, device=hidden_states.device)
         p = self.dropout_p if self.training else 0.0
         seed, site = ops.dropout_stream.next(3) if p > 0 else (0, 0)
-        return ops.tfm_layer(hidden_states, attention_mask, self.head_num, self.kernel_params(), p, seed, site, self.hf_mask)
+        return ops.tfm_layer(hidden_states, attention_mask, self.head_num, self.kernel_params(), p, seed, site, self.hf_mask,
+                             plan=plan)

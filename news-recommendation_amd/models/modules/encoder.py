@@ -107,6 +107,26 @@ class TfmNewsEncoder(BaseNewsEncoder):
         news, _ = ops.project_and_pool(tok, self.newsProject.weight, self.newsProject.bias, self.news_query, mask)
         return tok.view(*shape, -1), news.view(*shape[:-1], -1)
 
+    def news_vectors(self, token_id, attn_mask, title_keep=None):
+        """the news vectors alone, for callers that drop token_embedding (TwoTowerBaseModel.forward / encode_news):
+        same numbers as forward()[1], computed over the real token rows only (packed title tokens, include/newsrec_hip.h)
+        whenever the masks are prefix-shaped and T <= 32; otherwise through forward().  title_keep [...] 0/1 marks
+        titles whose vector the caller never uses (masked history slots): they are not encoded and come back as zeros."""
+        shape = token_id.shape
+        T = shape[-1]
+        packed = ops.pack_titles(token_id.reshape(-1, T), attn_mask.reshape(-1, T), title_keep) if self.packable(T) else None
+        if packed is None:
+            return self.forward(token_id, attn_mask)[1]
+        ids_p, plan = packed
+        mask = attn_mask.reshape(-1, T)
+        emb = ops.embedding(self.embedding.weight, ids_p, self.embedding.padding_idx)        # [rows, E]
+        tok = self.transformer(emb, attention_mask=mask, plan=plan)
+        news, _ = ops.project_and_pool(tok, self.newsProject.weight, self.newsProject.bias, self.news_query, mask, plan=plan)
+        return news.view(*shape[:-1], -1)
+
+    def packable(self, T):
+        return T <= 32 and self.transformer.hidden_dim // self.transformer.head_num <= 64 and not getattr(self, "no_packing", False)
+
 
 class _BertEmbeddings(nn.Module):
     """parameter container with HF BertEmbeddings' names"""
@@ -217,6 +237,13 @@ class AllBertNewsEncoder(BaseNewsEncoder):
 
 
 class RnnUserEncoder(BaseUserEncoder):
+    @staticmethod
+    def history_keep(his_mask):
+        """[B,L] 0/1: the history slots that can reach the result.  The packed GRU reads the first len = sum(his_mask)
+        slots and nothing else (reference encoder.py:226-232)."""
+        L = his_mask.shape[1]
+        return (torch.arange(L, device=his_mask.device)[None, :] < his_mask.sum(1, keepdim=True)).long()
+
     """final GRU state over the clicked-news vectors (the default -ue of main.twotower).  ``self.rnn`` is an
     nn.GRU used as a parameter container only (reference key names rnn.weight_ih_l0 …); the recurrence runs
     in the HIP library (input half as one MFMA GEMM, 2 small launches per step, no lens.cpu() sync)."""
@@ -262,6 +289,12 @@ class AttnUserEncoder(BaseUserEncoder):
 
 
 class TfmUserEncoder(BaseUserEncoder):
+    @staticmethod
+    def history_keep(his_mask):
+        """[B,L] 0/1: his_mask == 0 slots are masked keys of the layer and of the pooling (weight exactly 0, reference
+        encoder.py:325-326 / attention.py:24,90) and their own rows are dropped by the pooling the same way."""
+        return (his_mask != 0).long()
+
     def __init__(self, manager):
         super().__init__()
         self.transformer = TFMLayer(manager.hidden_dim, manager.head_num, 0.1)

@@ -81,6 +81,15 @@ _SIGS = {
     "nr_tfm_layer_bwd_ws_bytes": (c_sz, [c_i64, c_i64, c_i64]),
     "nr_tfm_layer_bwd_f32": (c_int, [c_fp, c_fp, c_fp, c_i64, c_i64, c_i64, c_i64, C.POINTER(TfmWeights), c_f, c_u64,
                                      c_u32, c_int, C.POINTER(TfmSaved), C.POINTER(TfmGrads), c_fp, c_fp, c_sz, c_fp]),
+    "nr_pack_plan": (c_int, [c_fp, c_fp, c_i64, c_i64, c_fp, c_fp, c_fp]),
+    "nr_pack_ids": (c_int, [c_fp, c_fp, c_i64, c_i64, c_fp, c_fp, c_fp]),
+    "nr_tfm_layer_packed_fwd_f32": (c_int, [c_fp, c_fp, c_fp, c_fp, c_i64, c_i64, c_i64, c_i64, c_i64, C.POINTER(TfmWeights), c_f, c_u64,
+                                            c_u32, c_int, C.POINTER(TfmSaved), c_fp, c_fp]),
+    "nr_tfm_layer_packed_bwd_f32": (c_int, [c_fp, c_fp, c_fp, c_fp, c_fp, c_i64, c_i64, c_i64, c_i64, c_i64, C.POINTER(TfmWeights), c_f,
+                                            c_u64, c_u32, c_int, C.POINTER(TfmSaved), C.POINTER(TfmGrads), c_fp, c_fp, c_sz, c_fp]),
+    "nr_query_pool_packed_fwd_f32": (c_int, [c_fp, c_fp, c_fp, c_i64, c_fp, c_fp, c_i64, c_i64, c_i64, c_fp, c_fp, c_fp]),
+    "nr_query_pool_packed_bwd_f32": (c_int, [c_fp, c_fp, c_fp, c_i64, c_fp, c_fp, c_fp, c_i64, c_i64, c_i64, c_int,
+                                             c_fp, c_fp, c_fp, c_fp, c_sz, c_fp]),
     "nr_gru_fwd_ws_bytes": (c_sz, [c_i64, c_i64]),
     "nr_gru_fwd_f32": (c_int, [c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_i64, c_i64, c_i64, c_i64, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp,
                                c_sz, c_fp]),

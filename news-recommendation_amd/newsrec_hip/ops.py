@@ -116,6 +116,40 @@ def embedding(table, ids, padding_idx=PAD_ID):
     return _Embedding.apply(_f32(table, "embedding.weight"), _i64(ids, "token_id"), padding_idx)
 
 
+# ----------------------------------------------------------------------------- packed title tokens
+class PackPlan:
+    """row layout of N titles with the padded positions removed (include/newsrec_hip.h, "packed title tokens"):
+    offs [N+1] int32, row_map [rows] int32 (packed row -> n*T + j), rows = offs[N]."""
+    __slots__ = ("offs", "row_map", "rows", "N", "T")
+
+    def __init__(self, offs, row_map, rows, N, T):
+        self.offs, self.row_map, self.rows, self.N, self.T = offs, row_map, rows, N, T
+
+
+def pack_titles(ids, mask, title_keep=None):
+    """ids / mask [N,T] int64 on the device -> (ids_packed [rows] int64, PackPlan), or None when a mask row is not
+    prefix-shaped (the packing is exact only for those; the caller then takes the padded path).  title_keep [N] 0/1:
+    titles with 0 get no rows at all (the caller guarantees nothing downstream uses their vectors).  One 8-byte
+    device->host read (the row count sizes every later allocation)."""
+    ids, mask = _i64(ids, "token_id"), _i64(mask, "attn_mask")
+    N, T = mask.shape
+    if title_keep is not None:
+        title_keep = _i64(title_keep, "title_keep").reshape(-1)
+        if title_keep.numel() != N:
+            raise NewsrecError(f"pack_titles: title_keep has {title_keep.numel()} entries for {N} titles")
+    offs = torch.empty(N + 1, dtype=torch.int32, device=mask.device)
+    info = torch.empty(2, dtype=torch.int32, device=mask.device)
+    L = lib()
+    check(L.nr_pack_plan(_p(mask), _p(title_keep), N, T, _p(offs), _p(info), _stream()), "nr_pack_plan")
+    rows, ok = info.tolist()
+    if not ok:
+        return None
+    ids_packed = torch.empty(rows, dtype=torch.int64, device=mask.device)
+    row_map = torch.empty(rows, dtype=torch.int32, device=mask.device)
+    check(L.nr_pack_ids(_p(ids), _p(offs), N, T, _p(ids_packed), _p(row_map), _stream()), "nr_pack_ids")
+    return ids_packed, PackPlan(offs, row_map, int(rows), N, T)
+
+
 # ----------------------------------------------------------------------------- linear
 ACT = {"none": 0, "relu": 1, "gelu": 2, "tanh": 3}
 
@@ -228,28 +262,34 @@ def _carve(device, sizes):
 
 class _TFMLayer(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, mask, H, p, seed, site, mask_mode, *params):
-        N, S, D = x.shape
-        R = N * S
+    def forward(ctx, x, mask, H, p, seed, site, mask_mode, plan, *params):
+        N, S = mask.shape
+        D = x.shape[-1]
+        R = N * S if plan is None else plan.rows      # packed: x is [R, D]
         train = any(ctx.needs_input_grad)       # False under no_grad / eval-only calls
         sizes = [3 * D * D, 3 * D, R * 3 * D, R * D, R * D, R * D, R * 4 * D if train else 0, R * 4 * D, R * D,
                  4 * R if train else 0, N * H * S if train else 0, N * H * S if train else 0]
         buf, (wqkv, bqkv, qkv, cx, s1, y1, z, a, s2, stats, rmax, rsum) = _carve(x.device, sizes)
-        y = torch.empty(N, S, D, dtype=torch.float32, device=x.device)
+        y = torch.empty_like(x)
         W = TfmWeights(*[_p(t) for t in params])
         SV = TfmSaved(_p(wqkv), _p(bqkv), _p(qkv), _p(cx), _p(s1), _p(y1), _p(z) if train else None, _p(a), _p(s2),
                       _p(stats) if train else None, _p(rmax) if train else None, _p(rsum) if train else None)
-        check(lib().nr_tfm_layer_fwd_f32(_p(x), _p(mask), N, S, D, H, C.byref(W), p, seed, site, mask_mode, C.byref(SV),
-                                        _p(y), _stream()), "nr_tfm_layer_fwd_f32")
+        if plan is None:
+            check(lib().nr_tfm_layer_fwd_f32(_p(x), _p(mask), N, S, D, H, C.byref(W), p, seed, site, mask_mode, C.byref(SV),
+                                            _p(y), _stream()), "nr_tfm_layer_fwd_f32")
+        else:
+            check(lib().nr_tfm_layer_packed_fwd_f32(_p(x), _p(mask), _p(plan.offs), _p(plan.row_map), N, S, R, D, H, C.byref(W), p, seed,
+                                                   site, mask_mode, C.byref(SV), _p(y), _stream()), "nr_tfm_layer_packed_fwd_f32")
         if train:
             ctx.save_for_backward(x, mask, buf, *params)
-            ctx.cfg = (N, S, D, H, p, seed, site, mask_mode, sizes)
+            ctx.cfg = (N, S, D, H, p, seed, site, mask_mode, sizes, plan)
         return y
 
     @staticmethod
     def backward(ctx, g):
         x, mask, buf, *params = ctx.saved_tensors
-        N, S, D, H, p, seed, site, mask_mode, sizes = ctx.cfg
+        N, S, D, H, p, seed, site, mask_mode, sizes, plan = ctx.cfg
+        R = N * S if plan is None else plan.rows
         g = _f32(g, "grad")
         offs, tot = [], 0
         for s in sizes:
@@ -266,21 +306,31 @@ class _TFMLayer(torch.autograd.Function):
         G = TfmGrads(*[_p(grads[n]) for n in _TFM_ORDER])
         dx = torch.empty_like(x)
         L = lib()
-        nbytes = L.nr_tfm_layer_bwd_ws_bytes(N, S, D)
+        nbytes = L.nr_tfm_layer_bwd_ws_bytes(R, 1, D)
         ws = _ws(nbytes, g.device)
-        check(L.nr_tfm_layer_bwd_f32(_p(g), _p(x), _p(mask), N, S, D, H, C.byref(W), p, seed, site, mask_mode, C.byref(SV),
-                                     C.byref(G), _p(dx), _p(ws), ws.numel() * 4, _stream()), "nr_tfm_layer_bwd_f32")
-        return (dx, None, None, None, None, None, None) + tuple(grads[n] for n in _TFM_ORDER)
+        if plan is None:
+            check(L.nr_tfm_layer_bwd_f32(_p(g), _p(x), _p(mask), N, S, D, H, C.byref(W), p, seed, site, mask_mode, C.byref(SV),
+                                         C.byref(G), _p(dx), _p(ws), ws.numel() * 4, _stream()), "nr_tfm_layer_bwd_f32")
+        else:
+            check(L.nr_tfm_layer_packed_bwd_f32(_p(g), _p(x), _p(mask), _p(plan.offs), _p(plan.row_map), N, S, R, D, H, C.byref(W), p,
+                                                seed, site, mask_mode, C.byref(SV), C.byref(G), _p(dx), _p(ws), ws.numel() * 4,
+                                                _stream()), "nr_tfm_layer_packed_bwd_f32")
+        return (dx, None, None, None, None, None, None, None) + tuple(grads[n] for n in _TFM_ORDER)
 
 
-def tfm_layer(x, mask, head_num, params, p_drop=0.0, seed=0, site=0, hf_mask=False):
+def tfm_layer(x, mask, head_num, params, p_drop=0.0, seed=0, site=0, hf_mask=False, plan=None):
     """TFMLayer.forward (attention.py:173-182).  x [N,S,D] fp32, mask [N,S] int64 (1 = real),
     params: dict with keys wq,bq,wk,bk,wv,bv,wo,bo,ln1_g,ln1_b,w1,b1,w2,b2,ln2_g,ln2_b.
     hf_mask: key-mask semantics of HF BertModel under SDPA (masked keys excluded; no valid key -> zero
-    context) instead of the reference layer's additive -1e5."""
+    context) instead of the reference layer's additive -1e5.
+    plan: a PackPlan from pack_titles -> x is the packed [rows, D] matrix and so is the result."""
     x = _f32(x, "hidden_states")
     mask = _i64(mask, "attention_mask")
-    if x.dim() != 3 or mask.shape != x.shape[:2]:
+    if plan is not None:
+        if x.dim() != 2 or x.shape[0] != plan.rows or tuple(mask.shape) != (plan.N, plan.T):
+            raise NewsrecError(f"tfm_layer: packed x {tuple(x.shape)} / mask {tuple(mask.shape)} do not match the plan "
+                               f"({plan.rows} rows, {plan.N} x {plan.T})")
+    elif x.dim() != 3 or mask.shape != x.shape[:2]:
         raise NewsrecError(f"tfm_layer: x {tuple(x.shape)} / mask {tuple(mask.shape)} shape mismatch")
     plist = [_f32(params[n], n) for n in _TFM_ORDER]
     D = x.shape[-1]
@@ -288,7 +338,7 @@ def tfm_layer(x, mask, head_num, params, p_drop=0.0, seed=0, site=0, hf_mask=Fal
         want = {"w1": (4 * D, D), "b1": (4 * D,), "w2": (D, 4 * D)}.get(n, (D, D) if n.startswith("w") else (D,))
         if tuple(t.shape) != want:
             raise NewsrecError(f"tfm_layer: parameter {n} has shape {tuple(t.shape)}, expected {want}")
-    return _TFMLayer.apply(x, mask, int(head_num), float(p_drop), int(seed), int(site), 1 if hf_mask else 0, *plist)
+    return _TFMLayer.apply(x, mask, int(head_num), float(p_drop), int(seed), int(site), 1 if hf_mask else 0, plan, *plist)
 
 
 # ----------------------------------------------------------------------------- GRU user encoder
@@ -429,39 +479,52 @@ class _ProjPool(torch.autograd.Function):
     """out = softmax(q . tanh(x W^T + b)^T / sqrt(D) + mask) . x  — encoder.py:57,141,326."""
 
     @staticmethod
-    def forward(ctx, x, w, b, query, mask):
-        nseq, S, D = x.shape
+    def forward(ctx, x, w, b, query, mask, plan):
+        nseq, S = mask.shape
+        D = x.shape[-1]
         x2 = x.view(-1, D)
         key = linear_fwd(x2, w, b, "tanh")
         out = torch.empty(nseq, D, dtype=torch.float32, device=x.device)
         prob = torch.empty(nseq, S, dtype=torch.float32, device=x.device)
-        check(lib().nr_query_pool_fwd_f32(_p(key), _p(x), None, None, 0, _p(query), _p(mask), nseq, S, D, _p(out), _p(prob),
-                                          _stream()), "nr_query_pool_fwd_f32")
+        if plan is None:
+            check(lib().nr_query_pool_fwd_f32(_p(key), _p(x), None, None, 0, _p(query), _p(mask), nseq, S, D, _p(out), _p(prob),
+                                              _stream()), "nr_query_pool_fwd_f32")
+        else:
+            check(lib().nr_query_pool_packed_fwd_f32(_p(key), _p(x), _p(plan.offs), plan.rows, _p(query), _p(mask), nseq, S, D,
+                                                     _p(out), _p(prob), _stream()), "nr_query_pool_packed_fwd_f32")
         ctx.save_for_backward(x, w, query, key, prob)
+        ctx.plan, ctx.dims = plan, (nseq, S, D)
         ctx.mark_non_differentiable(prob)
         return out, prob
 
     @staticmethod
     def backward(ctx, g, _gprob):
         x, w, query, key, prob = ctx.saved_tensors
-        nseq, S, D = x.shape
+        nseq, S, D = ctx.dims
+        plan = ctx.plan
+        R = nseq * S if plan is None else plan.rows
         g = _f32(g, "grad")
         L = lib()
-        dkeypre = torch.empty(nseq * S, D, dtype=torch.float32, device=g.device)
-        dvalue = torch.empty(nseq * S, D, dtype=torch.float32, device=g.device)
+        dkeypre = torch.empty(R, D, dtype=torch.float32, device=g.device)
+        dvalue = torch.empty(R, D, dtype=torch.float32, device=g.device)
         dq = torch.empty_like(query)
         ws = _ws(L.nr_query_pool_bwd_ws_bytes(nseq, D), g.device)
-        check(L.nr_query_pool_bwd_f32(_p(key), _p(x), _p(query), _p(prob), _p(g), nseq, S, D, 1, 0, _p(dkeypre), _p(dvalue),
-                                      _p(dq), _p(ws), ws.numel() * 4, _stream()), "nr_query_pool_bwd_f32")
-        dx = linear_bwd_input(dkeypre, w, 1, dvalue).view(nseq, S, D)       # dkeypre W + dvalue
+        if plan is None:
+            check(L.nr_query_pool_bwd_f32(_p(key), _p(x), _p(query), _p(prob), _p(g), nseq, S, D, 1, 0, _p(dkeypre), _p(dvalue),
+                                          _p(dq), _p(ws), ws.numel() * 4, _stream()), "nr_query_pool_bwd_f32")
+        else:
+            check(L.nr_query_pool_packed_bwd_f32(_p(key), _p(x), _p(plan.offs), R, _p(query), _p(prob), _p(g), nseq, S, D, 1,
+                                                 _p(dkeypre), _p(dvalue), _p(dq), _p(ws), ws.numel() * 4, _stream()),
+                  "nr_query_pool_packed_bwd_f32")
+        dx = linear_bwd_input(dkeypre, w, 1, dvalue).view(x.shape)          # dkeypre W + dvalue
         dw, db = linear_bwd_weight(dkeypre, x.view(-1, D))
-        return dx, dw, db, dq, None
+        return dx, dw, db, dq, None, None
 
 
-def project_and_pool(x, w, b, query, mask):
-    """x [nseq,S,D] -> (pooled [nseq,D], prob [nseq,S])."""
+def project_and_pool(x, w, b, query, mask, plan=None):
+    """x [nseq,S,D] (or packed [rows,D] with a PackPlan) -> (pooled [nseq,D], prob [nseq,S])."""
     return _ProjPool.apply(_f32(x, "x"), _f32(w, "project.weight"), _f32(b, "project.bias"), _f32(query, "query"),
-                           _i64(mask, "mask"))
+                           _i64(mask, "mask"), plan)
 
 
 class _Pool(torch.autograd.Function):

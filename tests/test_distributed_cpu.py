@@ -50,6 +50,7 @@ def _hook_oracle(model, O):
     def infer(x):
         return O.infer(P, "attn", model.news_embeddings, x["cdd_idx"], x["his_idx"], x["his_mask"])
     model._encode_news = enc
+    model._corpus_vectors = lambda x: enc(x)[1]
     model.infer = infer
 
 

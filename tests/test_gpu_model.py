@@ -33,7 +33,7 @@ def check_against_golden(tag, ne, ue):
     meta, P, X, Og, G, extra = load_golden(tag)
     model, mgr = build_model(meta, ne, ue)
     missing, unexpected = model.load_state_dict(P, strict=True), None      # reference key names must match exactly
-    # MIOpen's GRU backward refuses eval mode: stay in train mode with every dropout site at p = 0
+    # train mode with every dropout site at p = 0 (the golden vectors are eval-mode: torch's dropout stream is not portable)
     model = model.cuda().train()
     for m in model.modules():
         if hasattr(m, "dropout_p"):
@@ -41,6 +41,9 @@ def check_against_golden(tag, ne, ue):
     assert model.name == "TwoTower-{}-{}".format({"bert": "AllBert"}.get(ne, ne.capitalize()), ue.capitalize())
     tok, cdd = model._encode_news(X)
     _, his = model._encode_news(X, cdd=False)
+    if hasattr(model.newsEncoder, "news_vectors"):      # the packed-token path gives the same news vectors
+        assert relerr(model.newsEncoder.news_vectors(X["cdd_token_id"].cuda(), X["cdd_attn_mask"].cuda()), Og["cdd_news"]) < FP32_TOL
+        assert relerr(model.newsEncoder.news_vectors(X["his_token_id"].cuda(), X["his_attn_mask"].cuda()), Og["his_news"]) < FP32_TOL
     user = model._encode_user(X)
     logits = model._compute_logits(cdd, user)
     assert relerr(cdd, Og["cdd_news"]) < FP32_TOL
@@ -142,6 +145,164 @@ def test_tfm_layer_train_mode_with_dropout(N, S, D, H):
     ev = ops.tfm_layer(x.cuda(), mask.cuda(), H, layer.kernel_params(), 0.0, 0, 0)
     assert relerr(ev, O.tfm_layer(P, "t.", x, mask, H)) < FP32_TOL
     assert relerr(ev, out) > 1e-3
+
+
+def _packed_case(N, S, D, H, seed, with_empty):
+    from models.modules.attention import TFMLayer
+    torch.manual_seed(seed)
+    layer = TFMLayer(D, H, 0.1)
+    g = torch.Generator().manual_seed(seed + 1)
+    with torch.no_grad():
+        for n, p_ in layer.named_parameters():
+            if n.endswith("bias"):
+                p_.copy_(0.1 * torch.randn(p_.shape, generator=g))
+            if "LayerNorm.weight" in n:
+                p_.copy_(1 + 0.1 * torch.randn(p_.shape, generator=g))
+    x = torch.randn(N, S, D, generator=g)
+    lens = torch.randint(1, S + 1, (N,), generator=g)
+    if with_empty:
+        lens[::7] = 0                                   # titles without any real token keep all S rows
+        x[lens == 0] = x[0, 0].clone()                          # ... and are all-PAD: identical tokens (well conditioned)
+    mask = (torch.arange(S)[None] < lens[:, None]).long()
+    dy = torch.randn(N, S, D, generator=g)
+    return layer, x, lens, mask, dy
+
+
+@pytest.mark.parametrize("N,S,D,H", [(64, 32, 300, 12), (1760, 32, 300, 12), (40, 32, 768, 12), (9, 17, 24, 4)])
+def test_packed_layer_equals_padded_layer(N, S, D, H):
+    """packed title tokens (rows of padded positions removed) against the padded layout on the SAME kernels, train mode
+    with dropout: the forward rows of real tokens are bit-identical (dropout keep-bits are indexed by the original
+    position), all-PAD titles keep their S rows, and every gradient agrees (split-K order differs: tolerance)."""
+    from newsrec_hip import ops
+    layer, x, lens, mask, dy = _packed_case(N, S, D, H, 51, with_empty=True)
+    keep = (torch.arange(S)[None] < torch.where(lens > 0, lens, torch.tensor(S))[:, None])
+    layer = layer.cuda().train()
+    ids = torch.arange(N * S).view(N, S)
+    packed = ops.pack_titles(ids.cuda(), mask.cuda())
+    assert packed is not None
+    ids_p, plan = packed
+    row_map = keep.view(-1).nonzero().view(-1)
+    assert plan.rows == int(keep.sum()) and torch.equal(plan.row_map.cpu().long(), row_map) and torch.equal(ids_p.cpu(), row_map)
+    assert torch.equal(plan.offs.cpu().long(), torch.cat([torch.zeros(1, dtype=torch.long), keep.sum(1).cumsum(0)]))
+    seed, site, p = 0xABCDEF0123, 7, 0.1
+    dyk = dy * keep[..., None]                          # padded rows never receive gradient in the model (pooling prob 0)
+    xg = x.cuda().requires_grad_(True)
+    out = ops.tfm_layer(xg, mask.cuda(), H, layer.kernel_params(), p, seed, site)
+    out.backward(dyk.cuda())
+    ref_g = {n: p_.grad.clone() for n, p_ in layer.named_parameters()}
+    layer.zero_grad()
+    xp = x.view(-1, D)[row_map].cuda().requires_grad_(True)
+    outp = ops.tfm_layer(xp, mask.cuda(), H, layer.kernel_params(), p, seed, site, plan=plan)
+    outp.backward(dy.view(-1, D)[row_map].cuda())
+    assert torch.equal(outp, out.view(-1, D)[row_map.cuda()])
+    nonempty = (lens > 0)[:, None].expand(N, S).reshape(-1)[row_map].cuda()
+    assert relerr(xp.grad[nonempty], xg.grad.view(-1, D)[row_map.cuda()][nonempty]) < GRAD_TOL
+    assert relerr(xp.grad, xg.grad.view(-1, D)[row_map.cuda()]) < GRAD_TOL
+    gscale = max(float(v.abs().max()) for v in ref_g.values())
+    for n, p_ in layer.named_parameters():
+        assert (p_.grad - ref_g[n]).abs().max().item() <= GRAD_TOL * ref_g[n].abs().max().item() + 3e-6 * gscale, n
+
+
+def test_packed_layer_vs_oracle_train_mode():
+    """the packed layer against the CPU oracle (padded, reference arithmetic) with the library's keep-masks injected"""
+    from newsrec_hip import ops
+    N, S, D, H = 96, 32, 300, 12
+    layer, x, lens, mask, dy = _packed_case(N, S, D, H, 61, with_empty=False)
+    keep = mask.bool()
+    row_map = keep.view(-1).nonzero().view(-1)
+    P = _tfm_params_from_module(layer, "t.")
+    seed, site, p = 0x5EED5EED, 11, 0.1
+    masks = dict(probs=keep_mask((N, H, S, S), p, seed, site), attn_out=keep_mask((N, S, D), p, seed, site + 1),
+                 ffn_out=keep_mask((N, S, D), p, seed, site + 2))
+    Pr = {k: v.clone().requires_grad_(True) for k, v in P.items()}
+    xr = x.clone().requires_grad_(True)
+    ref = O.tfm_layer(Pr, "t.", xr, mask, H, drop_masks=masks, p=p)
+    ref.backward(dy * keep[..., None])
+    layer = layer.cuda().train()
+    ids_p, plan = ops.pack_titles(torch.zeros(N, S, dtype=torch.int64).cuda(), mask.cuda())
+    xp = x.view(-1, D)[row_map].cuda().requires_grad_(True)
+    outp = ops.tfm_layer(xp, mask.cuda(), H, layer.kernel_params(), p, seed, site, plan=plan)
+    outp.backward(dy.view(-1, D)[row_map].cuda())
+    assert relerr(outp, ref.view(-1, D)[row_map]) < FP32_TOL
+    assert relerr(xp.grad, xr.grad.view(-1, D)[row_map]) < GRAD_TOL
+    gscale = max(float(v.grad.abs().max()) for v in Pr.values())
+    for n, p_ in layer.named_parameters():
+        ref_g = Pr["t." + n].grad
+        assert (p_.grad.cpu() - ref_g).abs().max().item() <= GRAD_TOL * ref_g.abs().max().item() + 3e-6 * gscale, n
+
+
+def test_pack_refuses_non_prefix_masks():
+    """the packing is exact only for prefix-shaped masks: anything else makes pack_titles return None and the
+    encoder takes the padded path (same kernels, reference-equal)"""
+    from newsrec_hip import ops
+    mask = torch.ones(5, 8, dtype=torch.int64)
+    mask[2, 3] = 0                                      # a hole
+    assert ops.pack_titles(torch.zeros(5, 8, dtype=torch.int64).cuda(), mask.cuda()) is None
+    mask[2, 3:] = 0
+    assert ops.pack_titles(torch.zeros(5, 8, dtype=torch.int64).cuda(), mask.cuda()) is not None
+
+
+def test_news_vectors_packed_equals_padded_encoder():
+    """TfmNewsEncoder.news_vectors (packed rows) == TfmNewsEncoder.forward()[1] (padded, the reference layout), eval and
+    train mode, incl. the all-PAD news and news without a title; gradients of both agree"""
+    from newsrec_hip import ops
+    meta = dict(V=30522, E=300, D=300, H=12, T=32, L=50, K=4, B=4, Nn=500)
+    model, mgr = build_model(meta, "tfm", "tfm")
+    g = torch.Generator().manual_seed(91)
+    ids, msk = synth_news_table(g, meta["Nn"], meta["T"], meta["V"])
+    enc = model.newsEncoder.cuda()
+    ids_d, msk_d = ids.cuda().view(5, 100, -1), msk.cuda().view(5, 100, -1)
+    enc.eval()
+    with torch.no_grad():
+        a = enc(ids_d, msk_d)[1]
+        b = enc.news_vectors(ids_d, msk_d)
+    assert a.shape == b.shape == (5, 100, 300) and torch.equal(a, b)
+    enc.train()
+    outs = []
+    for fn in (lambda: enc(ids_d, msk_d)[1], lambda: enc.news_vectors(ids_d, msk_d)):
+        enc.zero_grad()
+        torch.manual_seed(3)
+        ops.dropout_stream.reset(0)
+        v = fn()
+        v.square().sum().backward()
+        outs.append((v.detach().clone(), {n: p_.grad.clone() for n, p_ in enc.named_parameters()}))
+    (va, ga), (vb, gb) = outs
+    assert torch.equal(va, vb)
+    gscale = max(float(v.abs().max()) for v in ga.values())
+    for n in ga:                                        # floor: key.bias gradients are analytically zero (rounding noise)
+        assert (gb[n] - ga[n]).abs().max().item() <= GRAD_TOL * ga[n].abs().max().item() + 3e-6 * gscale, n
+    enc.no_packing = True                               # the switch really selects the path
+    with torch.no_grad():
+        enc.eval()
+        assert torch.equal(enc.news_vectors(ids_d, msk_d), a)
+
+
+@pytest.mark.parametrize("ue", ["tfm", "rnn", "attn"])
+def test_forward_skips_dead_history_titles_exactly(ue):
+    """TwoTowerBaseModel.forward does not encode history titles the user encoder masks out (tfm / rnn; attn ignores
+    his_mask, so nothing is skipped there): loss and every gradient equal the all-titles padded computation, in train
+    mode with dropout (keep-bits indexed by original position)."""
+    from newsrec_hip import ops
+    meta = dict(V=30522, E=300, D=300, H=12, T=32, L=50, K=4, B=16, Nn=3000)
+    model, mgr = build_model(meta, "tfm", ue)
+    g = torch.Generator().manual_seed(101)
+    ids, msk = synth_news_table(g, meta["Nn"], meta["T"], meta["V"])
+    X = synth_batch(g, meta["B"], meta["K"] + 1, meta["L"], meta["Nn"], ids, msk)
+    model = model.cuda().train()
+    runs = []
+    for no_packing in (True, False):
+        model.newsEncoder.no_packing = no_packing
+        model.zero_grad(set_to_none=True)
+        torch.manual_seed(9)
+        ops.dropout_stream.reset(0)
+        loss = model(X)
+        loss.backward()
+        runs.append((loss.detach().clone(), {n: p_.grad.detach().clone() for n, p_ in model.named_parameters()}))
+    (l0, g0), (l1, g1) = runs
+    assert abs(l0.item() - l1.item()) <= 1e-6 * abs(l0.item())
+    gscale = max(float(v.abs().max()) for v in g0.values())
+    for n in g0:
+        assert (g1[n] - g0[n]).abs().max().item() <= GRAD_TOL * g0[n].abs().max().item() + 3e-6 * gscale, n
 
 
 def test_nrms_train_step_vs_oracle():
