@@ -265,7 +265,7 @@ int nr_add_layernorm_fwd_f32(const float* h, const float* x, int64_t x_period, c
 }
 
 size_t nr_layernorm_bwd_ws_bytes(int64_t R, int64_t D) {
-    return 2 * pad256((size_t)ln_bwd_blocks(R) * D) + pad256((size_t)colsum_chunks(ln_bwd_blocks(R)) * D);
+    return 2 * pad256((size_t)ln_bwd_blocks(R) * D) + pad256((size_t)2 * colsum_chunks(ln_bwd_blocks(R)) * D);
 }
 
 static int layernorm_bwd(const float* dy, const float* s_in, const float* mean, const float* rstd, const float* gamma, int64_t R,
@@ -274,10 +274,9 @@ static int layernorm_bwd(const float* dy, const float* s_in, const float* mean, 
     const int nb = ln_bwd_blocks(R);
     float* pg = bump(cur, (size_t)nb * D);
     float* pb = bump(cur, (size_t)nb * D);
-    float* part = bump(cur, (size_t)colsum_chunks(nb) * D);
+    float* part = bump(cur, (size_t)2 * colsum_chunks(nb) * D);
     if (int rc = ln_bwd(dy, s_in, mean, rstd, gamma, ds, dh, pg, pb, R, D, dc, s)) return rc;
-    if (int rc = colsum(pg, D, nb, D, dgamma, part, s)) return rc;
-    return colsum(pb, D, nb, D, dbeta, part, s);
+    return colsum2(pg, pb, nb, D, dgamma, dbeta, part, s);       // dgamma and dbeta in one launch pair
 }
 
 int nr_add_layernorm_bwd_f32(const float* dy, const float* s_in, const float* mean, const float* rstd, const float* gamma, int64_t R, int64_t D, float p_drop, uint64_t seed, uint32_t site, float* ds, float* dh, float* dgamma, float* dbeta, void* ws, size_t ws_bytes, void* stream) {

@@ -334,8 +334,10 @@ int ln_bwd(const float* dy, const float* sin, const float* mean, const float* rs
 // (column tiles, row chunks).  Each lane keeps 4 independent float4 accumulators in flight.
 template <int VEC>
 __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ in, int64_t ld, float* __restrict__ out,
-                                                     int64_t R, int N, int64_t rows_per_block) {
+                                                     int64_t R, int N, int64_t rows_per_block,
+                                                     const float* __restrict__ in_b, float* __restrict__ out_b) {
     __shared__ float red[16][64 + 1];
+    if (blockIdx.z == 1) { in = in_b; out = out_b; }          // a second, same-shaped problem in the same launch
     const int cx = threadIdx.x & 15, ry = threadIdx.x >> 4;
     const int c0 = blockIdx.x * 64 + cx * 4;
     const int64_t r0 = (int64_t)blockIdx.y * rows_per_block;
@@ -391,7 +393,7 @@ int colsum(const float* in, int64_t ld, int64_t R, int N, float* out, float* par
     const int ctiles = cdiv(N, 64);
     const bool vec = (N % 4 == 0) && (ld % 4 == 0) && aligned16(in);
     const int nchunk = part ? colsum_chunks(R) : 1;
-#define NR_COLSUM(V, GRID, IN, LD, OUT, ROWS, RPB) hipLaunchKernelGGL(colsum_kernel<V>, GRID, dim3(256), 0, s, IN, LD, OUT, ROWS, N, RPB)
+#define NR_COLSUM(V, GRID, IN, LD, OUT, ROWS, RPB) hipLaunchKernelGGL(colsum_kernel<V>, GRID, dim3(256), 0, s, IN, LD, OUT, ROWS, N, RPB, (const float*)nullptr, (float*)nullptr)
     if (nchunk == 1) {
         if (vec) NR_COLSUM(4, dim3(ctiles, 1), in, ld, out, R, std::max<int64_t>(R, 1));
         else     NR_COLSUM(1, dim3(ctiles, 1), in, ld, out, R, std::max<int64_t>(R, 1));
@@ -416,27 +418,38 @@ int colsum(const float* in, int64_t ld, int64_t R, int N, float* out, float* par
 // info[1] = 1 iff every mask row is prefix-shaped (mask[n][j] == (j < len[n])), the only form the packing is exact for.
 // title_keep (optional, [N] 0/1): titles the caller proves dead (history slots the user encoder masks out: their news
 // vectors never reach the loss and receive exactly zero gradient) get NO rows at all.
-__global__ __launch_bounds__(1024) void pack_plan_kernel(const int64_t* __restrict__ mask, const int64_t* __restrict__ title_keep,
-                                                         int64_t N, int T, int* __restrict__ offs, int* __restrict__ info) {
+// Stage 1, one wave per title: len'[n] into offs[n] (scanned in place by stage 2) and the prefix-shape check.
+__global__ __launch_bounds__(256) void pack_lens_kernel(const int64_t* __restrict__ mask, const int64_t* __restrict__ title_keep,
+                                                        int64_t N, int T, int* __restrict__ offs, int* __restrict__ info) {
+    const int lane = threadIdx.x & 63;
+    const int64_t n = (int64_t)blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6);
+    if (n >= N) return;
+    const int64_t* m = mask + n * T;
+    int len = 0;
+    for (int j0 = 0; j0 < T; j0 += 64) {
+        const int j = j0 + lane;
+        len += __popcll(__ballot(j < T && m[j] != 0));
+    }
+    bool bad = false;
+    for (int j0 = 0; j0 < T; j0 += 64) {
+        const int j = j0 + lane;
+        if (j < T && ((m[j] != 0) != (j < len))) bad = true;
+    }
+    if (__ballot(bad) != 0ull && lane == 0) info[1] = 1;            // violation marker (benign race: every writer stores 1)
+    if (lane == 0) offs[n] = (title_keep && title_keep[n] == 0) ? 0 : (len == 0 ? T : len);
+}
+
+// Stage 2, one workgroup: exclusive scan of offs[0..N) in place, offs[N] = info[0] = total
+__global__ __launch_bounds__(1024) void pack_scan_kernel(int64_t N, int* __restrict__ offs, int* __restrict__ info) {
     __shared__ int wsum[16];
     __shared__ int carry;
-    __shared__ int ok_all;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    if (tid == 0) { carry = 0; ok_all = 1; }
+    if (tid == 0) carry = 0;
     __syncthreads();
     for (int64_t base = 0; base < N; base += 1024) {
         const int64_t n = base + tid;
-        int len = 0, ok = 1;
-        if (n < N) {
-            const int64_t* m = mask + n * T;
-            for (int j = 0; j < T; ++j) len += m[j] != 0;
-            for (int j = 0; j < T; ++j) ok &= ((m[j] != 0) == (j < len));
-            if (len == 0) len = T;
-            if (title_keep && title_keep[n] == 0) len = 0;
-        }
-        if (!ok) ok_all = 0;                              // benign race: every writer stores 0
-        // inclusive scan of len over the 1024 threads: wave scan, then the 16 wave totals
-        int v = len;
+        const int len = n < N ? offs[n] : 0;
+        int v = len;                                       // inclusive scan over the 1024 threads: wave scan + 16 wave totals
 #pragma unroll
         for (int o = 1; o < 64; o <<= 1) {
             const int t = __shfl_up(v, o, 64);
@@ -451,7 +464,7 @@ __global__ __launch_bounds__(1024) void pack_plan_kernel(const int64_t* __restri
         if (tid == 1023) carry = pre + v;
         __syncthreads();
     }
-    if (tid == 0) { offs[N] = carry; info[0] = carry; info[1] = ok_all; }
+    if (tid == 0) { offs[N] = carry; info[0] = carry; info[1] = info[1] ? 0 : 1; }   // marker -> "all rows prefix-shaped"
 }
 
 // one wave per title: packed ids and the packed-row -> original-row map
@@ -468,13 +481,40 @@ __global__ __launch_bounds__(256) void pack_ids_kernel(const int64_t* __restrict
 }
 
 int pack_plan(const int64_t* mask, const int64_t* title_keep, int64_t N, int T, int* offs, int* info, hipStream_t s) {
-    hipLaunchKernelGGL(pack_plan_kernel, dim3(1), dim3(1024), 0, s, mask, title_keep, N, T, offs, info);
+    // info[1]: stage 1 raises it on a mask row that is not prefix-shaped, stage 2 turns it into the "all rows are" flag
+    if (hipMemsetAsync(info, 0, 2 * sizeof(int), s) != hipSuccess) { set_error("pack_plan: memset failed"); return NR_ERR_LAUNCH; }
+    if (N > 0) hipLaunchKernelGGL(pack_lens_kernel, dim3(cdiv(N, WAVES_PER_BLOCK)), dim3(256), 0, s, mask, title_keep, N, T, offs, info);
+    hipLaunchKernelGGL(pack_scan_kernel, dim3(1), dim3(1024), 0, s, N, offs, info);
     return check_launch("pack_plan");
 }
 int pack_ids(const int64_t* ids, const int* offs, int64_t N, int T, int64_t* ids_packed, int* row_map, hipStream_t s) {
     if (N == 0) return NR_OK;
     hipLaunchKernelGGL(pack_ids_kernel, dim3(cdiv(N, WAVES_PER_BLOCK)), dim3(256), 0, s, ids, offs, N, T, ids_packed, row_map);
     return check_launch("pack_ids");
+}
+
+// two same-shaped column sums in one launch pair (dgamma and dbeta partials of the LayerNorm backward):
+// out_a[n] = sum_r a[r,n], out_b[n] = sum_r b[r,n]; part: 2 * colsum_chunks(R) * N floats
+int colsum2(const float* a, const float* b, int64_t R, int N, float* out_a, float* out_b, float* part, hipStream_t s) {
+    if (N == 0) return NR_OK;
+    ProfScope prof(FAM_MISC, s, 2.0 * R * N * 4);
+    const int ctiles = cdiv(N, 64);
+    const bool vec = (N % 4 == 0) && aligned16(a, b);
+    const int nchunk = colsum_chunks(R);
+    float* part_b = part + (size_t)nchunk * N;
+#define NR_COLSUM2(V, GRID, INA, INB, OUTA, OUTB, ROWS, RPB) hipLaunchKernelGGL(colsum_kernel<V>, GRID, dim3(256), 0, s, INA, (int64_t)N, OUTA, ROWS, N, RPB, INB, OUTB)
+    if (nchunk == 1) {
+        if (vec) NR_COLSUM2(4, dim3(ctiles, 1, 2), a, b, out_a, out_b, R, std::max<int64_t>(R, 1));
+        else     NR_COLSUM2(1, dim3(ctiles, 1, 2), a, b, out_a, out_b, R, std::max<int64_t>(R, 1));
+        return check_launch("colsum2");
+    }
+    const int64_t rpb = cdiv(R, nchunk);
+    if (vec) NR_COLSUM2(4, dim3(ctiles, nchunk, 2), a, b, part, part_b, R, rpb);
+    else     NR_COLSUM2(1, dim3(ctiles, nchunk, 2), a, b, part, part_b, R, rpb);
+    if (N % 4 == 0) NR_COLSUM2(4, dim3(ctiles, 1, 2), (const float*)part, (const float*)part_b, out_a, out_b, (int64_t)nchunk, (int64_t)nchunk);
+    else            NR_COLSUM2(1, dim3(ctiles, 1, 2), (const float*)part, (const float*)part_b, out_a, out_b, (int64_t)nchunk, (int64_t)nchunk);
+#undef NR_COLSUM2
+    return check_launch("colsum2");
 }
 
 // ------------------------------------------------------------------ small elementwise helpers

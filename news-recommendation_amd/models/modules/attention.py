@@ -106,7 +106,27 @@ class TFMLayer(nn.Module):
         self.intermediate = TFMIntermediate(hidden_dim=hidden_dim)
         self.output = TFMOutput(hidden_dim=hidden_dim, dropout_p=dropout_p)
 
+    def _coalesce_qkv(self):
+        """keep query|key|value weights (and biases) back to back in memory: the layer multiplies by ONE [3D, D] operand,
+        and contiguous parameters spare it six device copies per call.  The parameters stay three separate
+        nn.Parameters with the reference's names; only their storage is shared.  Re-done whenever .to()/.cuda() or a
+        load replaced the storage (the check is pointer arithmetic)."""
+        a = self.attention.self
+        ws, bs = (a.query.weight, a.key.weight, a.value.weight), (a.query.bias, a.key.bias, a.value.bias)
+        def contiguous3(ts):
+            n = ts[0].numel() * ts[0].element_size()
+            return all(t.is_contiguous() for t in ts) and ts[1].data_ptr() == ts[0].data_ptr() + n and ts[2].data_ptr() == ts[1].data_ptr() + n
+        if contiguous3(ws) and contiguous3(bs):
+            return
+        with torch.no_grad():
+            for ts in (ws, bs):
+                packed = torch.cat([t.data.reshape(-1) for t in ts])
+                n = ts[0].numel()
+                for k, t in enumerate(ts):
+                    t.data = packed[k * n:(k + 1) * n].view(t.shape)
+
     def kernel_params(self):
+        self._coalesce_qkv()
         a, i, o = self.attention, self.intermediate, self.output
         return dict(wq=a.self.query.weight, bq=a.self.query.bias, wk=a.self.key.weight, bk=a.self.key.bias,
                     wv=a.self.value.weight, bv=a.self.value.bias, wo=a.output.dense.weight, bo=a.output.dense.bias,
