@@ -148,6 +148,10 @@ int nr_score_bwd_f32(const float* cdd, const float* user, const float* dlogits, 
 /* ReLU backward from the saved output (self.Relu in encoder.py:56): out = y > 0 ? dy : 0. */
 int nr_relu_bwd_f32(const float* dy, const float* y, int64_t n, float* out, void* stream);
 
+/* erf-GELU backward from the saved pre-activation (TFMIntermediate used on its own, attention.py:135-144):
+ * out = dy * gelu'(z).  The fused layer folds this into the FFN2 dX GEMM's epilogue instead. */
+int nr_gelu_bwd_f32(const float* dy, const float* z, int64_t n, float* out, void* stream);
+
 /* ---- one post-LN transformer layer — TFMLayer, attention.py:161-182 -----------------------------
  * Fused driver over the kernels above (one C call per layer keeps the host off the critical path).
  * Weights use the reference's tensors unchanged ([out,in] row-major). */

@@ -433,6 +433,11 @@ int nr_relu_bwd_f32(const float* dy, const float* y, int64_t n, float* out, void
     return relu_bwd_f32(dy, y, out, n, S(stream));
 }
 
+int nr_gelu_bwd_f32(const float* dy, const float* z, int64_t n, float* out, void* stream) {
+    NR_CHECK_ARG(n >= 0 && (n == 0 || (dy && z && out)), "gelu_bwd: bad argument");
+    return gelu_bwd_f32(dy, z, out, n, S(stream));
+}
+
 int nr_adam_step_f32(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, double lr, double beta1, double beta2, double eps, int64_t step, void* stream) {
     NR_CHECK_ARG(n >= 0 && step >= 1, "adam_step: bad sizes");
     NR_CHECK_ARG(n == 0 || (param && grad && exp_avg && exp_avg_sq), "adam_step: null pointer");

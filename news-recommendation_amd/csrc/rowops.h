@@ -37,6 +37,7 @@ int conv_pack(const float* w, float* wf, float* wb, int D, int E, hipStream_t s)
 int conv_unpack_grad(const float* gwf, float* gw, int D, int E, hipStream_t s);
 int add_f32(const float* a, const float* b, float* o, int64_t n, hipStream_t s);
 int relu_bwd_f32(const float* dy, const float* y, float* o, int64_t n, hipStream_t s);
+int gelu_bwd_f32(const float* dy, const float* z, float* o, int64_t n, hipStream_t s);
 int mean_f32(const float* v, int n, float* out, hipStream_t s);
 int dropout_f32(const float* x, float* o, int64_t n, DropoutCfg dc, hipStream_t s);
 int add_bias_rows_f32(const float* x, const float* b, float* o, int64_t R, int D, hipStream_t s);

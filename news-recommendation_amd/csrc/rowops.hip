@@ -572,6 +572,17 @@ int relu_bwd_f32(const float* dy, const float* y, float* o, int64_t n, hipStream
     return check_launch("relu_bwd");
 }
 
+// out[i] = dy[i] * gelu'(z[i])    (erf-GELU backward from the saved pre-activation)
+__global__ void gelu_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ z, float* __restrict__ o, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        o[i] = dy[i] * gelu_grad_f(z[i]);
+}
+int gelu_bwd_f32(const float* dy, const float* z, float* o, int64_t n, hipStream_t s) {
+    if (n == 0) return NR_OK;
+    hipLaunchKernelGGL(gelu_bwd_kernel, dim3((int)std::min<int64_t>(cdiv(n, 256), 8192)), dim3(256), 0, s, dy, z, o, n);
+    return check_launch("gelu_bwd");
+}
+
 // out[i] = keep(i) ? x[i] / (1-p) : 0   (a dropout site that is not followed by a LayerNorm: BERT's embedding
 // dropout; the same call with the same (seed, site) is its backward)
 __global__ __launch_bounds__(256) void dropout_kernel(const float* __restrict__ x, float* __restrict__ o, int64_t n, DropoutCfg dc) {

@@ -85,9 +85,7 @@ class BaseModel(nn.Module):
             save_path = os.path.join(save_dir, "prediction.txt")
             with open(save_path, "w") as f:
                 for index, pred in enumerate(preds, 1):
-                    a = 1 - np.asarray(pred, dtype=np.float64)              # the reference ranks `1 - score` in float64
-                    ranks = 1 + (a[None, :] < a[:, None]).sum(axis=1)       # == scipy rankdata(a, method="min")
-                    f.write("{} [{}]\n".format(index, ",".join(str(int(r)) for r in ranks)))
+                    f.write("{} [{}]\n".format(index, ",".join(str(int(r)) for r in min_ranks(pred))))
             try:
                 subprocess.run(["zip", "-j", os.path.join(save_dir, "prediction.zip"), save_path], check=False)
             except OSError:
@@ -95,6 +93,14 @@ class BaseModel(nn.Module):
             self.logger.info("written to prediction at {}!".format(save_path))
         if manager.distributed:
             _barrier(self.device)
+
+
+def min_ranks(pred):
+    """1-based ranks of the candidates by descending score, ties sharing the smallest rank: what the reference gets from
+    scipy `ss.rankdata(1 - np.asarray(pred), method="min")` (models/BaseModel.py:141; its pred is a list of python floats,
+    so `1 - score` is formed in float64), restated as a comparison count."""
+    a = 1 - np.asarray(pred, dtype=np.float64)
+    return 1 + (a[None, :] < a[:, None]).sum(axis=1)
 
 
 def _barrier(device):

@@ -44,6 +44,24 @@ def extend_attention_mask(encoder_attention_mask):
     return (1 - m) * -1e5
 
 
+def _key_mask01(attention_mask, N, S, device):
+    """the sub-modules accept what the reference passes them — the EXTENDED additive mask [N,1,1,S] of
+    extend_attention_mask (0 or -1e5) — or a plain 0/1 mask [N,S], or None"""
+    if attention_mask is None:
+        return torch.ones(N, S, dtype=torch.int64, device=device)
+    m = attention_mask
+    if m.is_floating_point():
+        m = (m == 0)
+    return m.reshape(N, S).long()
+
+
+def _site_p(module):
+    """(p, seed, site) of a module's dropout site: nn.Dropout's p in train mode, else 0"""
+    p = float(module.dropout.p) if module.training else 0.0
+    seed, site = ops.dropout_stream.next(1) if p > 0 else (0, 0)
+    return p, seed, site
+
+
 class TFMSelfAttention(nn.Module):
     def __init__(self, hidden_dim, head_num, dropout_p):
         super().__init__()
@@ -55,6 +73,20 @@ class TFMSelfAttention(nn.Module):
         self.value = nn.Linear(hidden_dim, self.all_head_size)
         self.dropout = nn.Dropout(dropout_p)
 
+    def forward(self, hidden_states, attention_mask=None):
+        """[N,S,D] -> context [N,S,D] (reference attention.py:77-99): three dense layers + the attention core kernel.
+        TFMLayer does not call this (it runs the whole layer as one fused C call); it exists so that the public
+        sub-modules of the reference stay callable on their own."""
+        N, S, _ = hidden_states.shape
+        q = ops.linear(hidden_states, self.query.weight, self.query.bias)
+        k = ops.linear(hidden_states, self.key.weight, self.key.bias)
+        v = ops.linear(hidden_states, self.value.weight, self.value.bias)
+        qkv = torch.cat([q, k, v], dim=-1).view(N * S, 3 * self.all_head_size)
+        p, seed, site = _site_p(self)
+        ctx = ops.mhsa(qkv, _key_mask01(attention_mask, N, S, hidden_states.device), N, S, self.num_attention_heads,
+                       self.attention_head_size, p, seed, site)
+        return ctx.view(N, S, self.all_head_size)
+
 
 class TFMSelfOutput(nn.Module):
     def __init__(self, hidden_dim, dropout_p):
@@ -63,6 +95,12 @@ class TFMSelfOutput(nn.Module):
         self.LayerNorm = nn.LayerNorm(hidden_dim, eps=1e-12)
         self.dropout = nn.Dropout(dropout_p)
 
+    def forward(self, hidden_states, input_tensor):
+        """LayerNorm(dropout(dense(hidden_states)) + input_tensor) (reference attention.py:109-113)"""
+        h = ops.linear(hidden_states, self.dense.weight, self.dense.bias)
+        p, seed, site = _site_p(self)
+        return ops.add_layernorm(h, input_tensor, self.LayerNorm.weight, self.LayerNorm.bias, self.LayerNorm.eps, p, seed, site)
+
 
 class TFMAttention(nn.Module):
     def __init__(self, hidden_dim, head_num, dropout_p):
@@ -70,11 +108,18 @@ class TFMAttention(nn.Module):
         self.self = TFMSelfAttention(hidden_dim=hidden_dim, head_num=head_num, dropout_p=dropout_p)
         self.output = TFMSelfOutput(hidden_dim=hidden_dim, dropout_p=dropout_p)
 
+    def forward(self, hidden_states, attention_mask=None):
+        return self.output(self.self(hidden_states, attention_mask), hidden_states)
+
 
 class TFMIntermediate(nn.Module):
     def __init__(self, hidden_dim):
         super().__init__()
         self.dense = nn.Linear(hidden_dim, 4 * hidden_dim)
+
+    def forward(self, hidden_states):
+        """erf-GELU(dense(hidden_states)) (reference attention.py:141-144)"""
+        return ops.linear_gelu(hidden_states, self.dense.weight, self.dense.bias)
 
 
 class TFMOutput(nn.Module):
@@ -83,6 +128,12 @@ class TFMOutput(nn.Module):
         self.dense = nn.Linear(4 * hidden_dim, hidden_dim)
         self.LayerNorm = nn.LayerNorm(hidden_dim, eps=1e-12)
         self.dropout = nn.Dropout(dropout_p)
+
+    def forward(self, hidden_states, input_tensor):
+        """LayerNorm(dropout(dense(hidden_states)) + input_tensor) (reference attention.py:154-158)"""
+        h = ops.linear(hidden_states, self.dense.weight, self.dense.bias)
+        p, seed, site = _site_p(self)
+        return ops.add_layernorm(h, input_tensor, self.LayerNorm.weight, self.LayerNorm.bias, self.LayerNorm.eps, p, seed, site)
 
 
 class TFMLayer(nn.Module):

@@ -75,6 +75,7 @@ _SIGS = {
     "nr_score_fwd_f32": (c_int, [c_fp, c_fp, c_fp, c_i64, c_fp, c_fp, c_i64, c_i64, c_i64, c_fp, c_fp, c_fp, c_fp]),
     "nr_score_ce_bwd_f32": (c_int, [c_fp, c_fp, c_fp, c_fp, c_fp, c_i64, c_i64, c_i64, c_fp, c_fp, c_fp]),
     "nr_score_bwd_f32": (c_int, [c_fp, c_fp, c_fp, c_i64, c_i64, c_i64, c_fp, c_fp, c_fp]),
+    "nr_gelu_bwd_f32": (c_int, [c_fp, c_fp, c_i64, c_fp, c_fp]),
     "nr_relu_bwd_f32": (c_int, [c_fp, c_fp, c_i64, c_fp, c_fp]),
     "nr_tfm_layer_fwd_f32": (c_int, [c_fp, c_fp, c_i64, c_i64, c_i64, c_i64, C.POINTER(TfmWeights), c_f, c_u64, c_u32, c_int,
                                      C.POINTER(TfmSaved), c_fp, c_fp]),

@@ -206,6 +206,106 @@ def linear(x, w, b=None):
     return _Linear.apply(_f32(x, "x"), _f32(w, "weight"), None if b is None else _f32(b, "bias"))
 
 
+class _LinearGelu(torch.autograd.Function):
+    """gelu(x W^T + b) with the exact erf GELU (TFMIntermediate, attention.py:135-144)"""
+
+    @staticmethod
+    def forward(ctx, x, w, b):
+        x2 = x.reshape(-1, x.shape[-1])
+        z = torch.empty(x2.shape[0], w.shape[0], dtype=torch.float32, device=x.device)
+        y = linear_fwd(x2, w, b, "gelu", z)
+        ctx.save_for_backward(x2, w, z)
+        ctx.xshape = x.shape
+        return y.view(*x.shape[:-1], w.shape[0])
+
+    @staticmethod
+    def backward(ctx, g):
+        x2, w, z = ctx.saved_tensors
+        g2 = _f32(g, "grad").reshape(-1, w.shape[0])
+        dz = torch.empty_like(g2)
+        check(lib().nr_gelu_bwd_f32(_p(g2), _p(z), g2.numel(), _p(dz), _stream()), "nr_gelu_bwd_f32")
+        dx = linear_bwd_input(dz, w).view(ctx.xshape) if ctx.needs_input_grad[0] else None
+        dw, db = linear_bwd_weight(dz, x2, True)
+        return dx, dw, db
+
+
+def linear_gelu(x, w, b):
+    return _LinearGelu.apply(_f32(x, "x"), _f32(w, "weight"), _f32(b, "bias"))
+
+
+class _AddLayerNorm(torch.autograd.Function):
+    """LayerNorm(dropout(h) + x) (TFMSelfOutput / TFMOutput, attention.py:109-113,154-158)"""
+
+    @staticmethod
+    def forward(ctx, h, x, gamma, beta, eps, p, seed, site):
+        D = h.shape[-1]
+        h2, x2 = h.reshape(-1, D), x.reshape(-1, D)
+        R = h2.shape[0]
+        y = torch.empty_like(h2)
+        s = torch.empty_like(h2)
+        stats = torch.empty(2, R, dtype=torch.float32, device=h.device)
+        check(lib().nr_add_layernorm_fwd_f32(_p(h2), _p(x2), 0, _p(gamma), _p(beta), R, D, eps, p, seed, site, _p(y), _p(s),
+                                             _p(stats[0]), _p(stats[1]), _stream()), "nr_add_layernorm_fwd_f32")
+        ctx.save_for_backward(s, stats, gamma)
+        ctx.cfg = (R, D, p, seed, site, h.shape)
+        return y.view(h.shape)
+
+    @staticmethod
+    def backward(ctx, g):
+        s, stats, gamma = ctx.saved_tensors
+        R, D, p, seed, site, shape = ctx.cfg
+        g = _f32(g, "grad").reshape(R, D)
+        L = lib()
+        ds = torch.empty(R, D, dtype=torch.float32, device=g.device)
+        dh = torch.empty(R, D, dtype=torch.float32, device=g.device) if p > 0 else None
+        dgamma = torch.empty(D, dtype=torch.float32, device=g.device)
+        dbeta = torch.empty(D, dtype=torch.float32, device=g.device)
+        ws = _ws(L.nr_layernorm_bwd_ws_bytes(R, D), g.device)
+        check(L.nr_add_layernorm_bwd_f32(_p(g), _p(s), _p(stats[0]), _p(stats[1]), _p(gamma), R, D, p, seed, site, _p(ds), _p(dh),
+                                         _p(dgamma), _p(dbeta), _p(ws), ws.numel() * 4, _stream()), "nr_add_layernorm_bwd_f32")
+        return (dh if dh is not None else ds).view(shape), ds.view(shape), dgamma, dbeta, None, None, None, None
+
+
+def add_layernorm(h, x, gamma, beta, eps=LN_EPS, p_drop=0.0, seed=0, site=0):
+    h, x = _f32(h, "hidden_states"), _f32(x, "input_tensor")
+    if h.shape != x.shape:
+        raise NewsrecError(f"add_layernorm: {tuple(h.shape)} vs {tuple(x.shape)}")
+    return _AddLayerNorm.apply(h, x, _f32(gamma, "LayerNorm.weight"), _f32(beta, "LayerNorm.bias"), float(eps), float(p_drop),
+                               int(seed), int(site))
+
+
+class _MHSA(torch.autograd.Function):
+    """softmax(q k^T / sqrt(dh) + mask) v per head (TFMSelfAttention core, attention.py:87-97) over qkv [N*S, 3*H*dh]"""
+
+    @staticmethod
+    def forward(ctx, qkv, mask, N, S, H, dh, p, seed, site, mask_mode):
+        A = H * dh
+        out = torch.empty(N * S, A, dtype=torch.float32, device=qkv.device)
+        rmax = torch.empty(N, H, S, dtype=torch.float32, device=qkv.device)
+        rsum = torch.empty(N, H, S, dtype=torch.float32, device=qkv.device)
+        check(lib().nr_mhsa_fwd_f32(_p(qkv), _p(mask), N, S, H, dh, p, seed, site, mask_mode, _p(out), _p(rmax), _p(rsum), _stream()),
+              "nr_mhsa_fwd_f32")
+        ctx.save_for_backward(qkv, mask, out, rmax, rsum)
+        ctx.cfg = (N, S, H, dh, p, seed, site, mask_mode)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        qkv, mask, out, rmax, rsum = ctx.saved_tensors
+        N, S, H, dh, p, seed, site, mask_mode = ctx.cfg
+        g = _f32(g, "grad")
+        dqkv = torch.empty_like(qkv)
+        check(lib().nr_mhsa_bwd_f32(_p(qkv), _p(mask), _p(out), _p(g), _p(rmax), _p(rsum), N, S, H, dh, p, seed, site, mask_mode,
+                                    _p(dqkv), _stream()), "nr_mhsa_bwd_f32")
+        return (dqkv,) + (None,) * 9
+
+
+def mhsa(qkv, mask, N, S, H, dh, p_drop=0.0, seed=0, site=0, hf_mask=False):
+    """qkv [N*S, 3*H*dh] (q | k | v per row), mask [N,S] 0/1 -> context [N*S, H*dh]"""
+    return _MHSA.apply(_f32(qkv, "qkv"), _i64(mask, "attention_mask"), int(N), int(S), int(H), int(dh), float(p_drop), int(seed),
+                       int(site), 1 if hf_mask else 0)
+
+
 # ----------------------------------------------------------------------------- conv1d(k=3, pad=1) + relu
 class _ConvRelu(torch.autograd.Function):
     @staticmethod

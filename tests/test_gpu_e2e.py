@@ -120,3 +120,35 @@ def test_device_side_batch_assembly_is_bit_exact(tmp_path, monkeypatch):
     model = TwoTowerModel(m_dev, E.CnnNewsEncoder(m_dev), E.AttnUserEncoder(m_dev)).to(m_dev.device).eval()
     model.attach_news_tokens(d_dev.token_ids, d_dev.attn_masks)
     assert float(model(xb_dev)) == float(model(xb_host))
+
+
+def test_main_twotower_test_mode_writes_prediction_file(tmp_path, monkeypatch):
+    """`-m test` through main.twotower.main (reference BaseModel.py:126-152,292-329): the corpus is encoded, the test
+    impressions are scored from the cache and prediction.txt holds, per impression, the 1-based ranks of its
+    candidates — equal to scipy's rankdata(1 - score, "min") (the reference's expression) on the scores `_test` returns."""
+    import scipy.stats as ss
+    from utils.manager import Manager
+    from utils.synthetic import write_synthetic_caches
+    from main import twotower
+    from models.TwoTower import TwoTowerModel
+    from models.modules import encoder as E
+    monkeypatch.chdir(tmp_path)
+    base = f"-ne tfm -ue tfm -hd 48 -hn 4 -is 6 -s demo --synthetic-plm -cr {tmp_path}/cache -dr {tmp_path}/data"
+    m = Manager({"enable_fields": ["title"]}, command=("-m test " + base).split())
+    m.news_nums = {"MINDdemo_train": 300, "MINDdemo_dev": 200, "MINDdemo_test": 250}
+    write_synthetic_caches(m, n_train_impr=8, n_dev_impr=8, seed=6, splits=("test",))
+    # a checkpoint to load (-m test defaults to -ck best)
+    m.setup(m.device)
+    torch.manual_seed(5)
+    model = TwoTowerModel(m, E.TfmNewsEncoder(m), E.TfmUserEncoder(m)).to(m.device)
+    m.save(model, 1, best=True)
+    twotower.main(m.device, m)
+    path = os.path.join("data/cache/results", model.name, "demo", "best", "prediction.txt")
+    lines = open(path).read().splitlines()
+    loaders = m.prepare()
+    with torch.no_grad():
+        preds = model.eval()._test(m, loaders)
+    assert len(lines) == len(preds) == 8 and any(len(p) > 6 for p in preds)        # impressions span several 6-candidate rows
+    for i, (line, p) in enumerate(zip(lines, preds), 1):
+        want = ss.rankdata(1 - np.asarray(p), method="min")
+        assert line == "{} [{}]".format(i, ",".join(str(int(r)) for r in want))

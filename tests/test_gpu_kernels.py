@@ -315,6 +315,11 @@ def test_mhsa(ops, N, S, H, dh, p):
                                 N, S, H, dh, p, seed, site, 0, dq.data_ptr(), st))
     if N > 2:
         assert relerr(dq[2 * S:], qr.grad[2 * S:]) < 2e-5
+        # sequence 1: fully masked with IDENTICAL tokens (what an all-PAD title is) -> exactly uniform probabilities,
+        # well conditioned: its backward is held to the same bar
+        assert relerr(dq[S:2 * S], qr.grad[S:2 * S]) < 5e-5
+        # sequence 0: fully masked with different tokens, ill-conditioned by construction (see above)
+        assert relerr(dq[:S], qr.grad[:S]) < 5e-2
 
 
 def test_mhsa_masked_quantisation_exact(ops):

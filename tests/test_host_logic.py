@@ -279,3 +279,24 @@ def test_wordpiece_equals_hf_tokenizer_on_fuzzed_text(tmp_path):
     for _ in range(3000):
         s = "".join(rng.choice(pool) for _ in range(rng.randint(0, 30)))
         assert tok.encode(s, 16) == hf.encode(s, max_length=16, truncation=True), repr(s)
+
+
+def test_min_rank_restatement_equals_scipy_rankdata():
+    """BaseModel.test ranks `1 - score` with scipy's rankdata(method="min") in the reference (models/BaseModel.py:141);
+    the product restates it as a comparison count.  Checked against scipy itself (ties, duplicates, one element) and
+    against the reference-generated ranking fixture."""
+    import os
+    import scipy.stats as ss
+    from models.BaseModel import min_ranks
+    from helpers import GOLDEN
+    rng = np.random.RandomState(3)
+    cases = [np.asarray([0.5]), np.asarray([0.2, 0.2, 0.2]), np.asarray([0.5, 0.2, 0.5, 0.5, 0.1]),
+             np.round(rng.randn(300), 1).astype(np.float32), rng.randn(57).astype(np.float32)]
+    for a in cases:
+        assert np.array_equal(min_ranks(a), ss.rankdata(1 - np.asarray(a), method="min"))
+    z = np.load(os.path.join(GOLDEN, "rank_tfm_tfm.npz"), allow_pickle=False)
+    scores = z["logits"][z["cdd_mask"]]
+    order = np.argsort(z["impr_index"].repeat(z["cdd_mask"].sum(1)), kind="stable")
+    sizes = [int(v) for v in z["rank_sizes"]]
+    got = np.concatenate([min_ranks(g) for g in np.split(scores[order], np.cumsum(sizes)[:-1])])
+    assert np.array_equal(got, z["ranks"])
