@@ -215,6 +215,19 @@ int nr_tfm_layer_packed_bwd_f32(const float* dy, const float* x, const int64_t* 
 int nr_query_pool_packed_fwd_f32(const float* key, const float* value, const int32_t* offs, int64_t R, const float* query, const int64_t* mask, int64_t nseq, int64_t S, int64_t D, float* out, float* prob, void* stream);
 int nr_query_pool_packed_bwd_f32(const float* key, const float* value, const int32_t* offs, int64_t R, const float* query, const float* prob, const float* dout, int64_t nseq, int64_t S, int64_t D, int tanh_key, float* dkeypre, float* dvalue, float* dquery, void* ws, size_t ws_bytes, void* stream);
 
+/* ---- bf16 build: building blocks (tensors in HBM as bf16 = raw uint16; no counterpart in the reference, whose closest
+ * thing is torch.autocast over encoder.py:62-77) ---------------------------------------------------------
+ * nr_cast_bf16: y = bf16(x), round to nearest even.
+ * nr_transpose_bf16: dst [C, Rp] = bf16(src [R, C])^T, columns R..Rp-1 zero (Rp % 64 == 0): the transposed,
+ *   reduction-padded operand copies that bring dX = dY.W and dW = dY^T.X to the one form the bf16 GEMM takes.
+ * nr_gemm_nt_bf16: C[m,n] = act(sum_k A[m,k] B[n,k] + bias[n]); A [M,K], B [N,K] bf16, K % 64 == 0, f32 accumulate on
+ *   v_mfma_f32_32x32x16_bf16; results as f32 (C, may be NULL) and / or bf16 (Ch, may be NULL); act as nr_linear_fwd_f32
+ *   (2 = gelu also stores the pre-activation as bf16 in zh when given).  split_k != 0: f32 C only, no bias/act, slabs in ws. */
+int nr_cast_bf16(const float* x, int64_t n, uint16_t* y, void* stream);
+int nr_transpose_bf16(const void* src, int src_is_bf16, int64_t R, int64_t C, int64_t ld, uint16_t* dst, int64_t Rp, void* stream);
+size_t nr_gemm_nt_bf16_ws_bytes(int64_t M, int64_t N, int64_t K, int split_k);
+int nr_gemm_nt_bf16(const uint16_t* A, const uint16_t* B, const float* bias, int64_t M, int64_t N, int64_t K, int act, float* C, uint16_t* Ch, uint16_t* zh, int split_k, void* ws, size_t ws_bytes, void* stream);
+
 /* ---- GRU user encoder — RnnUserEncoder, models/modules/encoder.py:204-233 -----------------------------
  * One-layer nn.GRU(Din, H, batch_first) over x [B,L,Din], packed by len_b = sum_l mask[b,l] (>= 1: the
  * reference sets his_mask[b,0] = 1 for an empty history, dataset.py:140-141); the user vector is the state

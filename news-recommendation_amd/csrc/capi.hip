@@ -438,6 +438,31 @@ int nr_gelu_bwd_f32(const float* dy, const float* z, int64_t n, float* out, void
     return gelu_bwd_f32(dy, z, out, n, S(stream));
 }
 
+// ------------------------------------------------------------------------------------ bf16 build: building blocks
+int nr_cast_bf16(const float* x, int64_t n, uint16_t* y, void* stream) {
+    NR_CHECK_ARG(n >= 0 && (n == 0 || (x && y)), "cast_bf16: bad argument");
+    return cast_bf16(x, y, n, S(stream));
+}
+
+int nr_transpose_bf16(const void* src, int src_is_bf16, int64_t R, int64_t Cn, int64_t ld, uint16_t* dst, int64_t Rp, void* stream) {
+    NR_CHECK_ARG(R >= 0 && Cn >= 0 && (R == 0 || Cn == 0 || (src && dst)), "transpose_bf16: bad argument");
+    return transpose_bf16(src, src_is_bf16, ld, R, Cn, dst, Rp, S(stream));
+}
+
+size_t nr_gemm_nt_bf16_ws_bytes(int64_t M, int64_t N, int64_t K, int split_k) {
+    return split_k ? gemm_h_workspace_bytes((int)M, (int)N, choose_ksplit_h((int)M, (int)N, (int)K)) + 256 : 0;
+}
+
+int nr_gemm_nt_bf16(const uint16_t* A, const uint16_t* B, const float* bias, int64_t M, int64_t N, int64_t K, int act, float* C, uint16_t* Ch, uint16_t* zh, int split_k, void* ws, size_t ws_bytes, void* stream) {
+    NR_CHECK_ARG(M >= 0 && N > 0 && K > 0, "gemm_nt_bf16: bad sizes");
+    NR_CHECK_ARG(act >= 0 && act <= 3, "gemm_nt_bf16: act %d not in 0..3", act);
+    GemmHParams p;
+    p.A = A; p.lda = K; p.B = B; p.ldb = K; p.M = (int)M; p.N = (int)N; p.K = (int)K;
+    p.C = C; p.ldc = N; p.Ch = Ch; p.ldch = N; p.bias = bias; p.epi = act; p.out2h = zh; p.ldout2h = N;
+    if (split_k) p.ksplit = choose_ksplit_h(p.M, p.N, p.K);
+    return gemm_h(p, (float*)ws, ws_bytes, S(stream));
+}
+
 int nr_adam_step_f32(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, double lr, double beta1, double beta2, double eps, int64_t step, void* stream) {
     NR_CHECK_ARG(n >= 0 && step >= 1, "adam_step: bad sizes");
     NR_CHECK_ARG(n == 0 || (param && grad && exp_avg && exp_avg_sq), "adam_step: null pointer");

@@ -38,6 +38,34 @@ struct GemmParams {
     float* csum_part = nullptr;
 };
 
+// bf16-in-HBM "NT" GEMM (gemm_h.hip): C[m,n] = epi(sum_k A[m,k] B[n,k] + bias[n]); A [M,K], B [N,K] bf16 k-contiguous
+// (raw 16-bit storage), f32 accumulate.  Outputs: C (f32, may be NULL) and / or Ch (bf16, may be NULL).
+struct GemmHParams {
+    const unsigned short* A = nullptr;
+    const unsigned short* B = nullptr;
+    int M = 0, N = 0, K = 0;                     // K a multiple of 64
+    int64_t lda = 0, ldb = 0;
+    float* C = nullptr;
+    int64_t ldc = 0;
+    unsigned short* Ch = nullptr;
+    int64_t ldch = 0;
+    const float* bias = nullptr;
+    int epi = EPI_NONE;                          // NONE | RELU | GELU (+ out2h = pre-activation) | TANH | ADD_AUX (aux f32) | MUL_GELU_GRAD (auxh bf16)
+    const float* aux = nullptr;
+    int64_t ldaux = 0;
+    const unsigned short* auxh = nullptr;
+    int64_t ldauxh = 0;
+    unsigned short* out2h = nullptr;
+    int64_t ldout2h = 0;
+    int ksplit = 1;                              // > 1: plain f32 C only, summed from slabs in the workspace
+    int64_t split_stride = 0;
+    int vec = 0;                                 // set by gemm_h(): every epilogue pointer / pitch allows 16-byte accesses
+};
+int gemm_h(GemmHParams p, float* workspace, size_t ws_bytes, hipStream_t s);
+int choose_ksplit_h(int M, int N, int K);
+size_t gemm_h_workspace_bytes(int M, int N, int ksplit);
+bool gemm_h_supported(int M, int N, int K);
+
 int gemm_f32(GemmParams p, bool a_kc, bool b_kc, float* workspace, size_t ws_bytes, hipStream_t s);
 size_t gemm_workspace_bytes(int M, int N, int ksplit);
 int choose_ksplit(int M, int N, int K);

@@ -1,0 +1,286 @@
+// bf16-in-HBM GEMM for the bf16 build of the BERT-sized layers (parity bar 1e-2):
+//
+//   C[m,n] = epi( sum_k A[m,k] * B[n,k] + bias[n] )      A [M,K], B [N,K]: bf16, k contiguous; f32 accumulate
+//
+// Every product of the layer is brought to this one "NT" form: forward x . W^T as is; dX = dY . W with a
+// transposed bf16 copy of W as B; dW = dY^T . X with transposed bf16 copies of dY and X (rowops: transpose_cast).
+// v_mfma_f32_32x32x16_bf16, workgroup tile 128 x 128 x 64, 4 waves 2x2 (wave tile 64 x 64), two LDS stages.
+// Operand tiles travel HBM -> LDS directly (global_load_lds, 16 B per lane: no staging registers, no conversion):
+// one wave instruction fills 1 KiB = 8 tile rows of 128 B.  The LDS image is lane-linear, so the bank swizzle sits on
+// the SOURCE address: 16-byte chunk c of tile row r lives at chunk c ^ ((r >> 1) & 7) — the 16 lanes of one
+// ds_read_b128 phase (16 consecutive rows, same logical chunk) then cover all 64 banks exactly once.
+// K must be a multiple of 64 (callers zero-pad the reduction dimension of transposed copies); M / N edges read a
+// clamped row and are not stored.
+#include "common.h"
+#include "gemm.h"
+
+namespace nr {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2v __attribute__((ext_vector_type(2)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x2v __attribute__((ext_vector_type(2)));
+
+constexpr int HM = 128, HN = 128, HK = 64;
+constexpr int H_TILE_BYTES = HM * HK * 2;            // 16 KiB per operand tile
+constexpr int H_STAGE_BYTES = 2 * H_TILE_BYTES;      // A + B
+constexpr int H_LDS_BYTES = 4 * 64 * 68 * 4;          // the epilogue's four [64][68] f32 tiles (> the two operand stages)
+
+__device__ __forceinline__ unsigned short f2bf(float v) {
+    const f32x2v t = {v, 0.f};
+    return (unsigned short)(__builtin_bit_cast(uint32_t, __builtin_convertvector(t, bf16x2v)) & 0xffffu);   // RNE (v_cvt_pk_bf16_f32)
+}
+__device__ __forceinline__ uint32_t pack2(float lo, float hi) {
+    const f32x2v t = {lo, hi};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(t, bf16x2v));
+}
+__device__ __forceinline__ float bf2f(unsigned short v) { return __builtin_bit_cast(float, (uint32_t)v << 16); }
+
+__global__ __launch_bounds__(256, 2) void gemm_h_kernel(const GemmHParams p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char hsm[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wid >> 1, wc = wid & 1;
+    const int l31 = lane & 31, h = lane >> 5;
+
+    const int tiles_n = (p.N + HN - 1) / HN;
+    const int tiles_m = (p.M + HM - 1) / HM;
+    const int ntile = tiles_m * tiles_n;
+    int bid = blockIdx.x;
+    {                                       // XCD-aware, bijective, slice-major over the whole grid (see gemm_f32_kernel)
+        const int G = ntile * p.ksplit;
+        const int q = G >> 3, r = G & 7, x = bid & 7, loc = bid >> 3;
+        bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + loc;
+    }
+    const int ks = bid / ntile;
+    bid -= ks * ntile;
+    const int tm = bid / tiles_n, tn = bid - tm * tiles_n;
+    const int m0 = tm * HM, n0 = tn * HN;
+
+    const int kt_total = p.K / HK;
+    const int kt_per = (kt_total + p.ksplit - 1) / p.ksplit;
+    const int kt_begin = ks * kt_per;
+    const int kt_end = min(kt_total, kt_begin + kt_per);
+
+    // per-lane source pointers of this wave's 4 + 4 fills per k-tile: fill c covers tile rows 8c .. 8c+7,
+    // lane -> row 8c + (lane >> 3), LDS chunk lane & 7 = logical chunk ^ ((row >> 1) & 7)
+    const unsigned short* ga[4];
+    const unsigned short* gb[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int c = wid + 4 * j;
+        const int row = 8 * c + (lane >> 3);
+        const int chunk = (lane & 7) ^ ((row >> 1) & 7);
+        const int ra = min(m0 + row, p.M - 1), rb = min(n0 + row, p.N - 1);
+        ga[j] = p.A + (int64_t)ra * p.lda + chunk * 8;
+        gb[j] = p.B + (int64_t)rb * p.ldb + chunk * 8;
+    }
+    auto stage = [&](int buf, int kt) {
+        unsigned char* As = hsm + buf * H_STAGE_BYTES;
+        unsigned char* Bs = As + H_TILE_BYTES;
+        const int k0 = kt * HK;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int c = wid + 4 * j;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(ga[j] + k0),
+                                             (__attribute__((address_space(3))) void*)(As + c * 1024), 16, 0, 0);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int c = wid + 4 * j;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gb[j] + k0),
+                                             (__attribute__((address_space(3))) void*)(Bs + c * 1024), 16, 0, 0);
+        }
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // fragment addresses: row (wr*64 + i*32 + l31) of A / (wc*64 + j*32 + l31) of B, logical chunk 2*s + h of k-step s
+    const int sw = (l31 >> 1) & 7;                        // tile-row offsets are multiples of 16: swizzle depends on l31 only
+    const int arow = (wr * 64 + l31) * 128, brow = (wc * 64 + l31) * 128;
+    auto compute = [&](int buf) {
+        const unsigned char* As = hsm + buf * H_STAGE_BYTES;
+        const unsigned char* Bs = As + H_TILE_BYTES;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const int co = ((2 * s + h) ^ sw) << 4;
+            bf16x8 fa[2], fb[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) fa[i] = *reinterpret_cast<const bf16x8*>(As + arow + i * 32 * 128 + co);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) fb[j] = *reinterpret_cast<const bf16x8*>(Bs + brow + j * 32 * 128 + co);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+        }
+    };
+
+    if (kt_begin < kt_end) {
+        stage(0, kt_begin);
+        __syncthreads();                                   // drains the fills (vmcnt(0)) and publishes them
+        int cur = 0;
+        for (int kt = kt_begin; kt < kt_end - 1; ++kt) {
+            stage(cur ^ 1, kt + 1);                        // next tile flies while this one is multiplied
+            compute(cur);
+            __syncthreads();
+            cur ^= 1;
+        }
+        compute(cur);
+    }
+
+    // ---- epilogue through LDS: each wave parks its 64 x 64 f32 tile in its own [64][68] region, then walks it row by
+    // row so that every global access is a 16-byte piece of a full 128-B line (bf16 rows of 64 columns) — the accumulator
+    // layout itself would store 2-byte elements 64 B at a time.  The epilogue math runs in this row-contiguous phase.
+    constexpr int EP = 68;
+    __syncthreads();                                       // every wave is done reading the operand stages
+    float* tile = reinterpret_cast<float*>(hsm) + wid * 64 * EP;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                tile[(i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h) * EP + j * 32 + l31] = acc[i][j][r];
+    __syncthreads();
+    const bool partial = p.ksplit > 1;
+    float* C = partial ? p.C + (int64_t)ks * p.split_stride : p.C;
+    const int64_t ldc = partial ? p.N : p.ldc;
+    const int epi = partial ? EPI_NONE : p.epi;
+    const bool ub = !partial && p.bias != nullptr;
+    unsigned short* Ch = partial ? nullptr : p.Ch;
+    const int mw = m0 + wr * 64, nw = n0 + wc * 64;
+    const int cc = (lane & 7) * 8;                          // 8 columns per lane, 8 rows per wave instruction
+    const int n = nw + cc;
+    const bool nfull = p.vec && n + 7 < p.N;
+    float bv[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) bv[e] = (ub && n + e < p.N) ? p.bias[n + e] : 0.f;
+#pragma unroll 2
+    for (int it = 0; it < 8; ++it) {
+        const int rr = it * 8 + (lane >> 3);
+        const int m = mw + rr;
+        if (m >= p.M || n >= p.N) continue;
+        float v[8];
+        {
+            const float4 t0 = *reinterpret_cast<const float4*>(tile + rr * EP + cc), t1 = *reinterpret_cast<const float4*>(tile + rr * EP + cc + 4);
+            v[0] = t0.x + bv[0]; v[1] = t0.y + bv[1]; v[2] = t0.z + bv[2]; v[3] = t0.w + bv[3];
+            v[4] = t1.x + bv[4]; v[5] = t1.y + bv[5]; v[6] = t1.z + bv[6]; v[7] = t1.w + bv[7];
+        }
+        if (epi == EPI_GELU) {
+            if (p.out2h) {
+                unsigned short* zp = p.out2h + (int64_t)m * p.ldout2h + n;
+                if (nfull) *reinterpret_cast<uint4*>(zp) = make_uint4(pack2(v[0], v[1]), pack2(v[2], v[3]), pack2(v[4], v[5]), pack2(v[6], v[7]));
+                else for (int e = 0; e < 8; ++e) if (n + e < p.N) zp[e] = f2bf(v[e]);
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = gelu_f(v[e]);
+        } else if (epi == EPI_ADD_AUX) {
+            const float* ap = p.aux + (int64_t)m * p.ldaux + n;
+            if (nfull) {
+                const float4 a0 = *reinterpret_cast<const float4*>(ap), a1 = *reinterpret_cast<const float4*>(ap + 4);
+                v[0] += a0.x; v[1] += a0.y; v[2] += a0.z; v[3] += a0.w; v[4] += a1.x; v[5] += a1.y; v[6] += a1.z; v[7] += a1.w;
+            } else for (int e = 0; e < 8; ++e) if (n + e < p.N) v[e] += ap[e];
+        } else if (epi == EPI_MUL_GELU_GRAD) {
+            const unsigned short* ap = p.auxh + (int64_t)m * p.ldauxh + n;
+            if (nfull) {
+                const uint4 u = *reinterpret_cast<const uint4*>(ap);
+                const uint32_t w[4] = {u.x, u.y, u.z, u.w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    v[2 * e] *= gelu_grad_f(__builtin_bit_cast(float, w[e] << 16));
+                    v[2 * e + 1] *= gelu_grad_f(__builtin_bit_cast(float, w[e] & 0xffff0000u));
+                }
+            } else for (int e = 0; e < 8; ++e) if (n + e < p.N) v[e] *= gelu_grad_f(bf2f(ap[e]));
+        } else if (epi == EPI_TANH) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = tanhf(v[e]);
+        } else if (epi == EPI_RELU) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
+        }
+        if (C) {
+            float* cp = C + (int64_t)m * ldc + n;
+            if (nfull) {
+                *reinterpret_cast<float4*>(cp) = make_float4(v[0], v[1], v[2], v[3]);
+                *reinterpret_cast<float4*>(cp + 4) = make_float4(v[4], v[5], v[6], v[7]);
+            } else for (int e = 0; e < 8; ++e) if (n + e < p.N) cp[e] = v[e];
+        }
+        if (Ch) {
+            unsigned short* hp = Ch + (int64_t)m * p.ldch + n;
+            if (nfull) *reinterpret_cast<uint4*>(hp) = make_uint4(pack2(v[0], v[1]), pack2(v[2], v[3]), pack2(v[4], v[5]), pack2(v[6], v[7]));
+            else for (int e = 0; e < 8; ++e) if (n + e < p.N) hp[e] = f2bf(v[e]);
+        }
+    }
+}
+
+// sum split-K slabs in a fixed order (deterministic) into C [M,N] (ldc)
+__global__ __launch_bounds__(256) void splitk_sum_kernel(const float* __restrict__ slabs, int ks, int64_t stride, float* __restrict__ C,
+                                                         int64_t ldc, int M, int N) {
+    const int64_t total = (int64_t)M * N;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+        const int m = (int)(idx / N), n = (int)(idx - (int64_t)m * N);
+        float v = 0.f;
+        for (int s = 0; s < ks; ++s) v += slabs[(int64_t)s * stride + idx];
+        C[(int64_t)m * ldc + n] = v;
+    }
+}
+
+int choose_ksplit_h(int M, int N, int K) {
+    const int tiles = cdiv(M, HM) * cdiv(N, HN);
+    const int kt = K / HK;
+    if (tiles >= 512 || kt < 8) return 1;
+    int ks = std::max(cdiv(512, tiles), kt / 16);         // fill the chip twice over, slices of ~16 k-tiles (1024 rows)
+    ks = std::min(ks, std::max(1, kt / 4));
+    return std::max(ks, 1);
+}
+
+size_t gemm_h_workspace_bytes(int M, int N, int ksplit) { return ksplit > 1 ? (size_t)ksplit * M * N * sizeof(float) : 0; }
+
+bool gemm_h_supported(int M, int N, int K) { return M >= 1 && N >= 1 && K >= HK && K % HK == 0; }
+
+int gemm_h(GemmHParams p, float* workspace, size_t ws_bytes, hipStream_t s) {
+    NR_CHECK_ARG(p.M >= 0 && p.N >= 0 && p.K >= 0, "gemm_h: negative dims");
+    if (p.M == 0 || p.N == 0) return NR_OK;
+    NR_CHECK_ARG(p.A && p.B && (p.C || p.Ch), "gemm_h: null operand");
+    NR_UNSUPPORTED(!gemm_h_supported(p.M, p.N, p.K), "gemm_h: K=%d must be a positive multiple of %d", p.K, HK);
+    auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
+    // 16-byte epilogue accesses need aligned bases and row pitches; anything else takes the element-wise path
+    p.vec = (!p.C || (p.ldc % 4 == 0 && al16(p.C))) && (!p.Ch || (p.ldch % 8 == 0 && al16(p.Ch))) && (!p.aux || (p.ldaux % 4 == 0 && al16(p.aux))) &&
+            (!p.auxh || (p.ldauxh % 8 == 0 && al16(p.auxh))) && (!p.out2h || (p.ldout2h % 8 == 0 && al16(p.out2h))) && (p.N % 8 == 0);
+    NR_CHECK_ARG(p.lda % 8 == 0 && p.ldb % 8 == 0 && ((reinterpret_cast<uintptr_t>(p.A) | reinterpret_cast<uintptr_t>(p.B)) & 15) == 0,
+                 "gemm_h: operands must be 16-byte aligned with row pitches that are multiples of 8 elements");
+    if (p.ksplit < 1) p.ksplit = 1;
+    float* final_c = p.C;
+    const int64_t final_ldc = p.ldc;
+    if (p.ksplit > 1) {
+        NR_CHECK_ARG(p.C && !p.Ch && p.epi == EPI_NONE && !p.bias, "gemm_h: split-K writes plain f32 results only");
+        const size_t need = gemm_h_workspace_bytes(p.M, p.N, p.ksplit);
+        if (!workspace || ws_bytes < need) { set_error("gemm_h: split-K workspace too small (%zu < %zu)", ws_bytes, need); return NR_ERR_WORKSPACE; }
+        p.C = workspace;
+        p.split_stride = (int64_t)p.M * p.N;
+    }
+    ProfScope prof(FAM_GEMM, s, 2.0 * p.M * p.N * p.K);
+    static bool once = false;
+    if (!once) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_h_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, H_LDS_BYTES); once = true; }
+    const int tiles = cdiv(p.M, HM) * cdiv(p.N, HN);
+    hipLaunchKernelGGL(gemm_h_kernel, dim3(tiles * p.ksplit), dim3(256), H_LDS_BYTES, s, p);
+    if (int rc = check_launch("gemm_h")) return rc;
+    if (p.ksplit > 1) {
+        const int64_t total = (int64_t)p.M * p.N;
+        const int grid = (int)std::min<int64_t>((total + 255) / 256, 4096);
+        hipLaunchKernelGGL(splitk_sum_kernel, dim3(grid), dim3(256), 0, s, (const float*)workspace, p.ksplit, p.split_stride, final_c, final_ldc, p.M, p.N);
+        return check_launch("splitk_sum");
+    }
+    return NR_OK;
+}
+
+}  // namespace nr

@@ -517,6 +517,91 @@ int colsum2(const float* a, const float* b, int64_t R, int N, float* out_a, floa
     return check_launch("colsum2");
 }
 
+// ------------------------------------------------------------------ bf16 shadow copies (the bf16 build, gemm_h.hip)
+typedef __bf16 rbf16x2 __attribute__((ext_vector_type(2)));
+typedef float rf32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t pack2_bf16(float lo, float hi) {
+    const rf32x2 v = {lo, hi};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, rbf16x2));        // RNE, v_cvt_pk_bf16_f32
+}
+// y[i] = bf16(x[i]); n % 8 == 0 and 16-byte aligned pointers take the vector path
+__global__ __launch_bounds__(256) void cast_bf16_kernel(const float* __restrict__ x, unsigned short* __restrict__ y, int64_t n, int vec) {
+    if (vec) {
+        const int64_t n8 = n >> 3;
+        for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (int64_t)gridDim.x * blockDim.x) {
+            const float4 a = *reinterpret_cast<const float4*>(x + 8 * i), b = *reinterpret_cast<const float4*>(x + 8 * i + 4);
+            uint4 o;
+            o.x = pack2_bf16(a.x, a.y); o.y = pack2_bf16(a.z, a.w); o.z = pack2_bf16(b.x, b.y); o.w = pack2_bf16(b.z, b.w);
+            *reinterpret_cast<uint4*>(y + 8 * i) = o;
+        }
+    } else {
+        for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+            y[i] = (unsigned short)(pack2_bf16(x[i], 0.f) & 0xffffu);
+    }
+}
+int cast_bf16(const float* x, unsigned short* y, int64_t n, hipStream_t s) {
+    if (n == 0) return NR_OK;
+    const int vec = (n % 8 == 0) && aligned16(x, y) ? 1 : 0;
+    ProfScope prof(FAM_MISC, s, (double)n * 6);
+    hipLaunchKernelGGL(cast_bf16_kernel, dim3((int)std::min<int64_t>(cdiv(vec ? n / 8 : n, 256), 16384)), dim3(256), 0, s, x, y, n, vec);
+    return check_launch("cast_bf16");
+}
+
+// dst[c][r] = bf16(src[r][c]) for r < R, 0 for R <= r < Rp: the transposed, reduction-padded copies that turn
+// dX = dY.W and dW = dY^T.X into the NT form of gemm_h.  64 x 64 tiles through LDS, both sides in full 128-B segments.
+template <bool SRC_H>
+__global__ __launch_bounds__(256) void transpose_bf16_kernel(const void* __restrict__ src_, int64_t ld, unsigned short* __restrict__ dst,
+                                                             int64_t R, int64_t Cn, int64_t Rp) {
+    __shared__ float t[64][65];
+    const int64_t r0 = (int64_t)blockIdx.x * 64, c0 = (int64_t)blockIdx.y * 64;
+    const int ty = threadIdx.x >> 4, tx = threadIdx.x & 15;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int rr = ty + 16 * i;
+        const int64_t r = r0 + rr, c = c0 + 4 * tx;
+        float v[4] = {0.f, 0.f, 0.f, 0.f};
+        if (r < R) {
+            if (c + 3 < Cn) {
+                if (SRC_H) {
+                    const uint2 u = *reinterpret_cast<const uint2*>(static_cast<const unsigned short*>(src_) + r * ld + c);
+                    v[0] = __builtin_bit_cast(float, u.x << 16); v[1] = __builtin_bit_cast(float, u.x & 0xffff0000u);
+                    v[2] = __builtin_bit_cast(float, u.y << 16); v[3] = __builtin_bit_cast(float, u.y & 0xffff0000u);
+                } else {
+                    const float4 f = *reinterpret_cast<const float4*>(static_cast<const float*>(src_) + r * ld + c);
+                    v[0] = f.x; v[1] = f.y; v[2] = f.z; v[3] = f.w;
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (c + e < Cn) v[e] = SRC_H ? __builtin_bit_cast(float, (uint32_t)static_cast<const unsigned short*>(src_)[r * ld + c + e] << 16)
+                                                 : static_cast<const float*>(src_)[r * ld + c + e];
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) t[rr][4 * tx + e] = v[e];
+    }
+    __syncthreads();
+    const int c = threadIdx.x >> 2, rq = threadIdx.x & 3;
+    if (c0 + c < Cn) {
+        uint32_t o[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) o[k] = pack2_bf16(t[16 * rq + 2 * k][c], t[16 * rq + 2 * k + 1][c]);
+        uint4* d = reinterpret_cast<uint4*>(dst + (c0 + c) * Rp + r0 + 16 * rq);
+        d[0] = make_uint4(o[0], o[1], o[2], o[3]);
+        d[1] = make_uint4(o[4], o[5], o[6], o[7]);
+    }
+}
+// src [R, Cn] (row pitch ld; f32, or bf16 when src_is_bf16; ld % 4 == 0) -> dst [Cn, Rp], Rp % 64 == 0, Rp >= R
+int transpose_bf16(const void* src, int src_is_bf16, int64_t ld, int64_t R, int64_t Cn, unsigned short* dst, int64_t Rp, hipStream_t s) {
+    if (Cn == 0 || Rp == 0) return NR_OK;
+    NR_CHECK_ARG(Rp % 64 == 0 && Rp >= R && ld % 4 == 0, "transpose_bf16: Rp=%lld must be a multiple of 64 >= R=%lld, ld %% 4 == 0", (long long)Rp, (long long)R);
+    ProfScope prof(FAM_MISC, s, (double)R * Cn * (src_is_bf16 ? 4 : 6));
+    const dim3 grid((unsigned)(Rp / 64), (unsigned)cdiv(Cn, 64));
+    if (src_is_bf16) hipLaunchKernelGGL(transpose_bf16_kernel<true>, grid, dim3(256), 0, s, src, ld, dst, R, Cn, Rp);
+    else             hipLaunchKernelGGL(transpose_bf16_kernel<false>, grid, dim3(256), 0, s, src, ld, dst, R, Cn, Rp);
+    return check_launch("transpose_bf16");
+}
+
 // ------------------------------------------------------------------ small elementwise helpers
 // conv weight re-layouts: w[D,E,3] <-> wf[D, 3E] (wf[d][kk*E+e] = w[d][e][kk]); and the
 // flipped/transposed one for dX: wb[e][kk*D+d] = w[d][e][2-kk]

@@ -91,6 +91,10 @@ _SIGS = {
     "nr_query_pool_packed_fwd_f32": (c_int, [c_fp, c_fp, c_fp, c_i64, c_fp, c_fp, c_i64, c_i64, c_i64, c_fp, c_fp, c_fp]),
     "nr_query_pool_packed_bwd_f32": (c_int, [c_fp, c_fp, c_fp, c_i64, c_fp, c_fp, c_fp, c_i64, c_i64, c_i64, c_int,
                                              c_fp, c_fp, c_fp, c_fp, c_sz, c_fp]),
+    "nr_cast_bf16": (c_int, [c_fp, c_i64, c_fp, c_fp]),
+    "nr_transpose_bf16": (c_int, [c_fp, c_int, c_i64, c_i64, c_i64, c_fp, c_i64, c_fp]),
+    "nr_gemm_nt_bf16_ws_bytes": (c_sz, [c_i64, c_i64, c_i64, c_int]),
+    "nr_gemm_nt_bf16": (c_int, [c_fp, c_fp, c_fp, c_i64, c_i64, c_i64, c_int, c_fp, c_fp, c_fp, c_int, c_fp, c_sz, c_fp]),
     "nr_gru_fwd_ws_bytes": (c_sz, [c_i64, c_i64]),
     "nr_gru_fwd_f32": (c_int, [c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_i64, c_i64, c_i64, c_i64, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp,
                                c_sz, c_fp]),
