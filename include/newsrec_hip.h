@@ -228,6 +228,22 @@ int nr_transpose_bf16(const void* src, int src_is_bf16, int64_t R, int64_t C, in
 size_t nr_gemm_nt_bf16_ws_bytes(int64_t M, int64_t N, int64_t K, int split_k);
 int nr_gemm_nt_bf16(const uint16_t* A, const uint16_t* B, const float* bias, int64_t M, int64_t N, int64_t K, int act, float* C, uint16_t* Ch, uint16_t* zh, int split_k, void* ws, size_t ws_bytes, void* stream);
 
+/* ---- the transformer layer of the bf16 build (AllBertNewsEncoder, encoder.py:62-77, parity bar 1e-2) ----
+ * Same layer, same argument meaning as nr_tfm_layer_{fwd,bwd}_f32; every GEMM operand (x, qkv, ctx, LN1 output,
+ * pre-GELU, GELU output and their gradients, plus bf16 copies of the weights made per call) and the attention tensors live
+ * in HBM as bf16; the residual stream, LayerNorm inputs / statistics, softmax arithmetic, accumulation and all parameter
+ * gradients are f32.  Needs D % 64 == 0, S <= 32, head dim <= 64, q|k|v weights / biases / gradients contiguous
+ * (packed [3D, D]); otherwise NR_ERR_UNSUPPORTED / NR_ERR_ARG and nothing runs.  R = N*S. */
+typedef struct {
+    uint16_t *x_h, *qkv_h, *ctx_h, *y1_h, *z_h, *a_h;   /* bf16 [R,D] [R,3D] [R,D] [R,D] [R,4D] [R,4D] */
+    float *s1, *y1, *s2;                                /* f32 [R,D]: drop(dense)+x, LN1 output (forward only), drop(dense)+y1 */
+    float *stats, *row_max, *row_sum;                   /* [4,R], [N,H,S], [N,H,S] */
+    uint16_t *w_h;                                      /* bf16 wqkv | wo | w1 | w2: 12 D^2 elements */
+} nr_tfm_saved_bf16;
+int nr_tfm_layer_fwd_bf16(const float* x, const int64_t* mask, int64_t N, int64_t S, int64_t D, int64_t H, const nr_tfm_weights* w, float p_drop, uint64_t seed, uint32_t site_base, int mask_mode, nr_tfm_saved_bf16* saved, float* y, void* stream);
+size_t nr_tfm_layer_bwd_bf16_ws_bytes(int64_t N, int64_t S, int64_t D);
+int nr_tfm_layer_bwd_bf16(const float* dy, const int64_t* mask, int64_t N, int64_t S, int64_t D, int64_t H, const nr_tfm_weights* w, float p_drop, uint64_t seed, uint32_t site_base, int mask_mode, const nr_tfm_saved_bf16* saved, nr_tfm_grads* grads, float* dx, void* ws, size_t ws_bytes, void* stream);
+
 /* ---- GRU user encoder — RnnUserEncoder, models/modules/encoder.py:204-233 -----------------------------
  * One-layer nn.GRU(Din, H, batch_first) over x [B,L,Din], packed by len_b = sum_l mask[b,l] (>= 1: the
  * reference sets his_mask[b,0] = 1 for an empty history, dataset.py:140-141); the user vector is the state

@@ -71,6 +71,72 @@ __device__ __forceinline__ void heads_in(float* tiles, const float* __restrict__
         }
     }
 }
+// the same for a bf16 tensor (the bf16 build keeps qkv / ctx and their gradients as bf16 in HBM; the tiles and all the
+// arithmetic stay f32): 16-byte pieces of 8 elements when the segment allows it
+template <int DHP>
+__device__ __forceinline__ void heads_in(float* tiles, const unsigned short* __restrict__ g, int64_t ld, int S, int dh, int nh, int tid, bool vec) {
+    constexpr int LD = DHP + 1, TS = 32 * LD;
+    const int W = nh * dh;
+    const int inv_dh = (1048576 + dh - 1) / dh;
+    if (vec && (W & 7) == 0) {
+        const int nq = W >> 3;
+        for (int idx = tid; idx < S * nq; idx += 256) {
+            const int r = idx / nq;
+            const int c = (idx - r * nq) << 3;
+            const uint4 u = *reinterpret_cast<const uint4*>(g + (int64_t)r * ld + c);
+            const uint32_t w[4] = {u.x, u.y, u.z, u.w};
+            int hh = fastdiv(c, inv_dh), d = c - hh * dh;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const uint32_t bits = (k & 1) ? (w[k >> 1] & 0xffff0000u) : (w[k >> 1] << 16);
+                tiles[hh * TS + r * LD + d] = __builtin_bit_cast(float, bits);
+                if (++d == dh) { d = 0; ++hh; }
+            }
+        }
+    } else {
+        for (int idx = tid; idx < S * W; idx += 256) {
+            const int r = idx / W;
+            const int c = idx - r * W;
+            const int hh = fastdiv(c, inv_dh);
+            tiles[hh * TS + r * LD + (c - hh * dh)] = __builtin_bit_cast(float, (uint32_t)g[(int64_t)r * ld + c] << 16);
+        }
+    }
+}
+typedef __bf16 abf16x2 __attribute__((ext_vector_type(2)));
+typedef float af32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t apack2(float lo, float hi) {
+    const af32x2 v = {lo, hi};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, abf16x2));
+}
+template <int DHP>
+__device__ __forceinline__ void heads_out(unsigned short* __restrict__ g, int64_t ld, const float* tiles, int S, int dh, int nh, int tid, bool vec) {
+    constexpr int LD = DHP + 1, TS = 32 * LD;
+    const int W = nh * dh;
+    const int inv_dh = (1048576 + dh - 1) / dh;
+    if (vec && (W & 7) == 0) {
+        const int nq = W >> 3;
+        for (int idx = tid; idx < S * nq; idx += 256) {
+            const int r = idx / nq;
+            const int c = (idx - r * nq) << 3;
+            int hh = fastdiv(c, inv_dh), d = c - hh * dh;
+            float e[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                e[k] = tiles[hh * TS + r * LD + d];
+                if (++d == dh) { d = 0; ++hh; }
+            }
+            *reinterpret_cast<uint4*>(g + (int64_t)r * ld + c) = make_uint4(apack2(e[0], e[1]), apack2(e[2], e[3]), apack2(e[4], e[5]), apack2(e[6], e[7]));
+        }
+    } else {
+        for (int idx = tid; idx < S * W; idx += 256) {
+            const int r = idx / W;
+            const int c = idx - r * W;
+            const int hh = fastdiv(c, inv_dh);
+            g[(int64_t)r * ld + c] = (unsigned short)(apack2(tiles[hh * TS + r * LD + (c - hh * dh)], 0.f) & 0xffffu);
+        }
+    }
+}
+
 template <int DHP>
 __device__ __forceinline__ void heads_out(float* __restrict__ g, int64_t ld, const float* tiles, int S, int dh, int nh, int tid, bool vec) {
     constexpr int LD = DHP + 1, TS = 32 * LD;
@@ -163,9 +229,9 @@ __device__ __forceinline__ unsigned keep_bits16(const DropoutCfg& dc, uint32_t t
     return bits;
 }
 
-template <int DHP>
-__global__ __launch_bounds__(256) void mhsa_fwd_mfma_kernel(const float* __restrict__ qkv, const int64_t* __restrict__ mask,
-                                                            float* __restrict__ ctx, float* __restrict__ row_max,
+template <int DHP, typename T>
+__global__ __launch_bounds__(256) void mhsa_fwd_mfma_kernel(const T* __restrict__ qkv, const int64_t* __restrict__ mask,
+                                                            T* __restrict__ ctx, float* __restrict__ row_max,
                                                             float* __restrict__ row_sum, int S, int H, int dh, DropoutCfg dc,
                                                             int vec) {
     constexpr int LD = DHP + 1, TS = 32 * LD;
@@ -186,7 +252,7 @@ __global__ __launch_bounds__(256) void mhsa_fwd_mfma_kernel(const float* __restr
     const int64_t row0 = dc.offs ? (int64_t)dc.offs[n] : (int64_t)n * S;
     const int Sn = dc.offs ? dc.offs[n + 1] - dc.offs[n] : S;
     if (Sn == 0) return;                                        // a title with no rows (block-uniform)
-    const float* base = qkv + row0 * ld + hd0 * dh;
+    const T* base = qkv + row0 * ld + hd0 * dh;
     heads_in<DHP>(Qt, base, ld, Sn, dh, nh, tid, vec);
     heads_in<DHP>(Kt, base + A, ld, Sn, dh, nh, tid, vec);
     heads_in<DHP>(Vt, base + 2 * A, ld, Sn, dh, nh, tid, vec);
@@ -242,10 +308,10 @@ __global__ __launch_bounds__(256) void mhsa_fwd_mfma_kernel(const float* __restr
     heads_out<DHP>(ctx + row0 * A + hd0 * dh, A, Qt, Sn, dh, nh, tid, vec);
 }
 
-template <int DHP>
-__global__ __launch_bounds__(256) void mhsa_bwd_mfma_kernel(const float* __restrict__ qkv, const int64_t* __restrict__ mask,
-                                                            const float* __restrict__ dctx, const float* __restrict__ row_max,
-                                                            const float* __restrict__ row_sum, float* __restrict__ dqkv,
+template <int DHP, typename T>
+__global__ __launch_bounds__(256) void mhsa_bwd_mfma_kernel(const T* __restrict__ qkv, const int64_t* __restrict__ mask,
+                                                            const T* __restrict__ dctx, const float* __restrict__ row_max,
+                                                            const float* __restrict__ row_sum, T* __restrict__ dqkv,
                                                             int S, int H, int dh, DropoutCfg dc, int vec) {
     constexpr int LD = DHP + 1, TS = 32 * LD;
     constexpr int DT = DHP / 32;
@@ -265,7 +331,7 @@ __global__ __launch_bounds__(256) void mhsa_bwd_mfma_kernel(const float* __restr
     const int64_t row0 = dc.offs ? (int64_t)dc.offs[n] : (int64_t)n * S;       // packed layout: see the forward kernel
     const int Sn = dc.offs ? dc.offs[n + 1] - dc.offs[n] : S;
     if (Sn == 0) return;
-    const float* base = qkv + row0 * ld + hd0 * dh;
+    const T* base = qkv + row0 * ld + hd0 * dh;
     heads_in<DHP>(Qt, base, ld, Sn, dh, nh, tid, vec);
     heads_in<DHP>(Kt, base + A, ld, Sn, dh, nh, tid, vec);
     heads_in<DHP>(Vt, base + 2 * A, ld, Sn, dh, nh, tid, vec);
@@ -340,7 +406,7 @@ __global__ __launch_bounds__(256) void mhsa_bwd_mfma_kernel(const float* __restr
         }
     }
     __syncthreads();                                           // K and V tiles are dead: reuse them as staging
-    float* dbase = dqkv + row0 * ld + hd0 * dh;
+    T* dbase = dqkv + row0 * ld + hd0 * dh;
     if (active) {
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt) {
@@ -373,40 +439,69 @@ static bool vec_ok(const void* a, const void* b, int H, int dh) {
            (H % HPG == 0 || (dh % 4 == 0));
 }
 
-int mhsa_fwd_mfma(const float* qkv, const int64_t* mask, float* ctx, float* row_max, float* row_sum, int64_t N, int S, int H,
-                  int dh, DropoutCfg dc, hipStream_t s) {
+template <typename T>
+static int launch_fwd(const T* qkv, const int64_t* mask, T* ctx, float* row_max, float* row_sum, int64_t N, int S, int H, int dh, DropoutCfg dc,
+                      int vec, hipStream_t s) {
     const int groups = (H + HPG - 1) / HPG;
     const dim3 grid((unsigned)(N * groups));
-    const int vec = vec_ok(qkv, ctx, H, dh) ? 1 : 0;
     const int dhp = dh <= 32 ? 32 : 64;
     const size_t lds = (size_t)3 * HPG * 32 * (dhp + 1) * sizeof(float);
     if (dhp == 32) {
-        hipLaunchKernelGGL(mhsa_fwd_mfma_kernel<32>, grid, dim3(256), lds, s, qkv, mask, ctx, row_max, row_sum, S, H, dh, dc, vec);
+        hipLaunchKernelGGL((mhsa_fwd_mfma_kernel<32, T>), grid, dim3(256), lds, s, qkv, mask, ctx, row_max, row_sum, S, H, dh, dc, vec);
     } else {
         static bool once = false;
-        if (!once) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mhsa_fwd_mfma_kernel<64>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); once = true; }
-        hipLaunchKernelGGL(mhsa_fwd_mfma_kernel<64>, grid, dim3(256), lds, s, qkv, mask, ctx, row_max, row_sum, S, H, dh, dc, vec);
+        if (!once) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mhsa_fwd_mfma_kernel<64, T>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); once = true; }
+        hipLaunchKernelGGL((mhsa_fwd_mfma_kernel<64, T>), grid, dim3(256), lds, s, qkv, mask, ctx, row_max, row_sum, S, H, dh, dc, vec);
     }
     return check_launch("mhsa_fwd_mfma");
 }
-
-int mhsa_bwd_mfma(const float* qkv, const int64_t* mask, const float* dctx, const float* row_max, const float* row_sum,
-                  float* dqkv, int64_t N, int S, int H, int dh, DropoutCfg dc, hipStream_t s) {
+template <typename T>
+static int launch_bwd(const T* qkv, const int64_t* mask, const T* dctx, const float* row_max, const float* row_sum, T* dqkv, int64_t N, int S,
+                      int H, int dh, DropoutCfg dc, int vec, hipStream_t s) {
     const int groups = (H + HPG - 1) / HPG;
     const dim3 grid((unsigned)(N * groups));
-    const int vec = (vec_ok(qkv, dctx, H, dh) && vec_ok(dqkv, dqkv, H, dh)) ? 1 : 0;
     const int dhp = dh <= 32 ? 32 : 64;
     const size_t lds = ((size_t)4 * HPG * 32 * (dhp + 1) + HPG * 128 + HPG * 32) * sizeof(float);
     if (dhp == 32) {
         static bool once = false;
-        if (!once) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mhsa_bwd_mfma_kernel<32>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); once = true; }
-        hipLaunchKernelGGL(mhsa_bwd_mfma_kernel<32>, grid, dim3(256), lds, s, qkv, mask, dctx, row_max, row_sum, dqkv, S, H, dh, dc, vec);
+        if (!once) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mhsa_bwd_mfma_kernel<32, T>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); once = true; }
+        hipLaunchKernelGGL((mhsa_bwd_mfma_kernel<32, T>), grid, dim3(256), lds, s, qkv, mask, dctx, row_max, row_sum, dqkv, S, H, dh, dc, vec);
     } else {
         static bool once = false;
-        if (!once) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mhsa_bwd_mfma_kernel<64>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); once = true; }
-        hipLaunchKernelGGL(mhsa_bwd_mfma_kernel<64>, grid, dim3(256), lds, s, qkv, mask, dctx, row_max, row_sum, dqkv, S, H, dh, dc, vec);
+        if (!once) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mhsa_bwd_mfma_kernel<64, T>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); once = true; }
+        hipLaunchKernelGGL((mhsa_bwd_mfma_kernel<64, T>), grid, dim3(256), lds, s, qkv, mask, dctx, row_max, row_sum, dqkv, S, H, dh, dc, vec);
     }
     return check_launch("mhsa_bwd_mfma");
+}
+
+int mhsa_fwd_mfma(const float* qkv, const int64_t* mask, float* ctx, float* row_max, float* row_sum, int64_t N, int S, int H,
+                  int dh, DropoutCfg dc, hipStream_t s) {
+    return launch_fwd<float>(qkv, mask, ctx, row_max, row_sum, N, S, H, dh, dc, vec_ok(qkv, ctx, H, dh) ? 1 : 0, s);
+}
+
+int mhsa_bwd_mfma(const float* qkv, const int64_t* mask, const float* dctx, const float* row_max, const float* row_sum,
+                  float* dqkv, int64_t N, int S, int H, int dh, DropoutCfg dc, hipStream_t s) {
+    return launch_bwd<float>(qkv, mask, dctx, row_max, row_sum, dqkv, N, S, H, dh, dc, (vec_ok(qkv, dctx, H, dh) && vec_ok(dqkv, dqkv, H, dh)) ? 1 : 0, s);
+}
+
+// bf16 tensors in HBM (raw 16-bit storage), f32 tiles and arithmetic; 16-byte pieces need A % 8 == 0 and aligned bases
+static bool vec_ok_h(const void* a, const void* b, int H, int dh) {
+    const int A = H * dh;
+    return (A % 8 == 0) && (((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b)) & 15) == 0) && ((HPG * dh) % 8 == 0);
+}
+int mhsa_fwd_mfma_h(const unsigned short* qkv, const int64_t* mask, unsigned short* ctx, float* row_max, float* row_sum, int64_t N, int S,
+                    int H, int dh, DropoutCfg dc, hipStream_t s) {
+    if (N == 0) return NR_OK;
+    NR_UNSUPPORTED(!mhsa_mfma_supported(S, dh), "mhsa (bf16 tensors): S=%d, head dim %d outside the matrix-core kernel (S <= 32, dh <= 64)", S, dh);
+    ProfScope prof(FAM_ATTN, s, 4.0 * N * H * S * S * dh);
+    return launch_fwd<unsigned short>(qkv, mask, ctx, row_max, row_sum, N, S, H, dh, dc, vec_ok_h(qkv, ctx, H, dh) ? 1 : 0, s);
+}
+int mhsa_bwd_mfma_h(const unsigned short* qkv, const int64_t* mask, const unsigned short* dctx, const float* row_max, const float* row_sum,
+                    unsigned short* dqkv, int64_t N, int S, int H, int dh, DropoutCfg dc, hipStream_t s) {
+    if (N == 0) return NR_OK;
+    NR_UNSUPPORTED(!mhsa_mfma_supported(S, dh), "mhsa bwd (bf16 tensors): S=%d, head dim %d outside the matrix-core kernel (S <= 32, dh <= 64)", S, dh);
+    ProfScope prof(FAM_ATTN, s, 10.0 * N * H * S * S * dh);
+    return launch_bwd<unsigned short>(qkv, mask, dctx, row_max, row_sum, dqkv, N, S, H, dh, dc, (vec_ok_h(qkv, dctx, H, dh) && vec_ok_h(dqkv, dqkv, H, dh)) ? 1 : 0, s);
 }
 
 }  // namespace nr

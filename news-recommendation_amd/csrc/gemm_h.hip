@@ -11,6 +11,12 @@
 // ds_read_b128 phase (16 consecutive rows, same logical chunk) then cover all 64 banks exactly once.
 // K must be a multiple of 64 (callers zero-pad the reduction dimension of transposed copies); M / N edges read a
 // clamped row and are not stored.
+// Measured (tools/gemm_h_bench.py, random operands): 775-800 TFLOP/s at 4096^3 / 8192^3, 540-750 at the BERT-base
+// shapes (R = 14 080 rows, K = 768 / 3072; one output).  That is the ceiling of this structure (two barriers per k-tile,
+// two workgroups per CU: the other workgroup's MFMAs are the only thing that overlaps a workgroup's wait for its fills).
+// Tried and dropped: BK = 32 with three stages, counted vmcnt + raw s_barrier and three workgroups per CU (two k-tiles
+// in flight per workgroup): 646 / 690 TFLOP/s at the cubes — half the MFMA work per barrier costs more than the deeper
+// queue buys.  Past ~0.9 PFLOP/s needs the 256 x 256, 8-wave, multi-phase schedule (next round).
 #include "common.h"
 #include "gemm.h"
 

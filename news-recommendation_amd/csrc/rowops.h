@@ -33,6 +33,7 @@ int pack_plan(const int64_t* mask, const int64_t* title_keep, int64_t N, int T, 
 int pack_ids(const int64_t* ids, const int* offs, int64_t N, int T, int64_t* ids_packed, int* row_map, hipStream_t s);
 int colsum(const float* in, int64_t ld, int64_t R, int N, float* out, float* part, hipStream_t s);
 int colsum2(const float* a, const float* b, int64_t R, int N, float* out_a, float* out_b, float* part, hipStream_t s);
+int colsum_h(const unsigned short* in, int64_t ld, int64_t R, int N, float* out, float* part, hipStream_t s);
 int cast_bf16(const float* x, unsigned short* y, int64_t n, hipStream_t s);
 int transpose_bf16(const void* src, int src_is_bf16, int64_t ld, int64_t R, int64_t Cn, unsigned short* dst, int64_t Rp, hipStream_t s);
 int conv_pack(const float* w, float* wf, float* wb, int D, int E, hipStream_t s);

@@ -328,11 +328,22 @@ int ln_bwd(const float* dy, const float* sin, const float* mean, const float* rs
     return check_launch("ln_bwd");
 }
 
+// 4 consecutive elements at element offset `off` of an f32 tensor, or of a bf16 one (IN_H: `p` is really 16-bit storage)
+template <bool IN_H>
+__device__ __forceinline__ float4 ld4(const float* p, int64_t off) {
+    if (IN_H) {
+        const uint2 u = *reinterpret_cast<const uint2*>(reinterpret_cast<const unsigned short*>(p) + off);
+        return make_float4(__builtin_bit_cast(float, u.x << 16), __builtin_bit_cast(float, u.x & 0xffff0000u),
+                           __builtin_bit_cast(float, u.y << 16), __builtin_bit_cast(float, u.y & 0xffff0000u));
+    }
+    return *reinterpret_cast<const float4*>(p + off);
+}
+
 // ------------------------------------------------------------------ column sums
 // out[n] = sum_r in[r, n]; two deterministic stages through `part` [nchunk, N].
 // Block = 16 column-quads (64 columns, 256 contiguous bytes per row) x 16 row lanes; grid =
 // (column tiles, row chunks).  Each lane keeps 4 independent float4 accumulators in flight.
-template <int VEC>
+template <int VEC, bool IN_H = false>
 __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ in, int64_t ld, float* __restrict__ out,
                                                      int64_t R, int N, int64_t rows_per_block,
                                                      const float* __restrict__ in_b, float* __restrict__ out_b) {
@@ -351,12 +362,12 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ i
             for (; r + 48 < r1; r += 64) {
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
-                    const float4 v = *reinterpret_cast<const float4*>(in + (r + 16 * u) * ld + c0);
+                    const float4 v = ld4<IN_H>(in, (r + 16 * u) * ld + c0);
                     a[u].x += v.x; a[u].y += v.y; a[u].z += v.z; a[u].w += v.w;
                 }
             }
             for (; r < r1; r += 16) {
-                const float4 v = *reinterpret_cast<const float4*>(in + r * ld + c0);
+                const float4 v = ld4<IN_H>(in, r * ld + c0);
                 a[0].x += v.x; a[0].y += v.y; a[0].z += v.z; a[0].w += v.w;
             }
         } else {
@@ -491,6 +502,21 @@ int pack_ids(const int64_t* ids, const int* offs, int64_t N, int T, int64_t* ids
     if (N == 0) return NR_OK;
     hipLaunchKernelGGL(pack_ids_kernel, dim3(cdiv(N, WAVES_PER_BLOCK)), dim3(256), 0, s, ids, offs, N, T, ids_packed, row_map);
     return check_launch("pack_ids");
+}
+
+// column sums of a bf16 [R,N] matrix (N % 4 == 0, 8-byte aligned rows) -> f32 out[N]; part as for colsum
+int colsum_h(const unsigned short* in, int64_t ld, int64_t R, int N, float* out, float* part, hipStream_t s) {
+    if (N == 0) return NR_OK;
+    NR_CHECK_ARG(N % 4 == 0 && ld % 4 == 0 && (reinterpret_cast<uintptr_t>(in) & 7) == 0 && part, "colsum_h: N, ld must be multiples of 4, rows 8-byte aligned");
+    ProfScope prof(FAM_MISC, s, (double)R * N * 2);
+    const int ctiles = cdiv(N, 64);
+    const int nchunk = colsum_chunks(R);
+    const int64_t rpb = cdiv(R, nchunk);
+    hipLaunchKernelGGL((colsum_kernel<4, true>), dim3(ctiles, nchunk), dim3(256), 0, s, reinterpret_cast<const float*>(in), ld, part, R, N, rpb,
+                       (const float*)nullptr, (float*)nullptr);
+    hipLaunchKernelGGL((colsum_kernel<4, false>), dim3(ctiles, 1), dim3(256), 0, s, (const float*)part, (int64_t)N, out, (int64_t)nchunk, N, (int64_t)nchunk,
+                       (const float*)nullptr, (float*)nullptr);
+    return check_launch("colsum_h");
 }
 
 // two same-shaped column sums in one launch pair (dgamma and dbeta partials of the LayerNorm backward):

@@ -18,6 +18,12 @@ int mhsa_fwd_mfma(const float* qkv, const int64_t* mask, float* ctx, float* row_
 int mhsa_bwd_mfma(const float* qkv, const int64_t* mask, const float* dctx, const float* row_max, const float* row_sum,
                   float* dqkv, int64_t N, int S, int H, int dh, DropoutCfg dc, hipStream_t s);
 
+// the same kernels over bf16 tensors in HBM (the bf16 build); tiles and arithmetic stay f32
+int mhsa_fwd_mfma_h(const unsigned short* qkv, const int64_t* mask, unsigned short* ctx, float* row_max, float* row_sum, int64_t N, int S,
+                    int H, int dh, DropoutCfg dc, hipStream_t s);
+int mhsa_bwd_mfma_h(const unsigned short* qkv, const int64_t* mask, const unsigned short* dctx, const float* row_max, const float* row_sum,
+                    unsigned short* dqkv, int64_t N, int S, int H, int dh, DropoutCfg dc, hipStream_t s);
+
 int pool_fwd(const float* key, const float* value, const float* table, const int64_t* idx, int64_t nrows, const float* query,
              const int64_t* mask, float* out, float* prob, int64_t nseq, int S, int D, hipStream_t s,
              const int* offs = nullptr, int64_t rows = 0);       // offs: packed sequences (rows = their total)

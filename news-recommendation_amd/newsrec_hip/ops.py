@@ -11,7 +11,7 @@ import math
 import torch
 
 from . import _lib
-from ._lib import NewsrecError, TfmWeights, TfmGrads, TfmSaved, check
+from ._lib import NewsrecError, TfmWeights, TfmGrads, TfmSaved, TfmSavedBf16, check
 
 PAD_ID = 0          # BERT word_embeddings.padding_idx (manager.special_token_ids["[PAD]"])
 LN_EPS = 1e-12      # models/modules/attention.py:106,151 of the reference
@@ -418,6 +418,63 @@ class _TFMLayer(torch.autograd.Function):
         return (dx, None, None, None, None, None, None, None) + tuple(grads[n] for n in _TFM_ORDER)
 
 
+class _TFMLayerBf16(torch.autograd.Function):
+    """the same layer in the bf16 build (nr_tfm_layer_{fwd,bwd}_bf16): GEMM operands and attention tensors are bf16 in HBM,
+    residual stream / LayerNorm / softmax / parameter gradients f32"""
+
+    @staticmethod
+    def forward(ctx, x, mask, H, p, seed, site, mask_mode, *params):
+        N, S, D = x.shape
+        R = N * S
+        dev = x.device
+        h = lambda *shape: torch.empty(*shape, dtype=torch.bfloat16, device=dev)
+        f = lambda *shape: torch.empty(*shape, dtype=torch.float32, device=dev)
+        bufs = dict(x_h=h(R, D), qkv_h=h(R, 3 * D), ctx_h=h(R, D), y1_h=h(R, D), z_h=h(R, 4 * D), a_h=h(R, 4 * D), s1=f(R, D), y1=f(R, D),
+                    s2=f(R, D), stats=f(4, R), row_max=f(N, H, S), row_sum=f(N, H, S), w_h=h(12 * D * D))
+        y = torch.empty_like(x)
+        W = TfmWeights(*[_p(t) for t in params])
+        SV = TfmSavedBf16(*[_p(bufs[n]) for n, _ in TfmSavedBf16._fields_])
+        check(lib().nr_tfm_layer_fwd_bf16(_p(x), _p(mask), N, S, D, H, C.byref(W), p, seed, site, mask_mode, C.byref(SV), _p(y), _stream()),
+              "nr_tfm_layer_fwd_bf16")
+        if any(ctx.needs_input_grad):
+            bufs.pop("y1"), bufs.pop("w_h")                 # forward-only scratch
+            ctx.names = list(bufs)
+            ctx.save_for_backward(mask, *bufs.values(), *params)
+            ctx.cfg = (N, S, D, H, p, seed, site, mask_mode)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        N, S, D, H, p, seed, site, mask_mode = ctx.cfg
+        saved = ctx.saved_tensors
+        mask, rest = saved[0], saved[1:]
+        bufs = dict(zip(ctx.names, rest[:len(ctx.names)]))
+        params = rest[len(ctx.names):]
+        g = _f32(g, "grad")
+        W = TfmWeights(*[_p(t) for t in params])
+        SV = TfmSavedBf16(*[_p(bufs.get(n)) for n, _ in TfmSavedBf16._fields_])
+        gqkv_w = torch.empty(3, D, D, dtype=torch.float32, device=g.device)
+        gqkv_b = torch.empty(3, D, dtype=torch.float32, device=g.device)
+        grads = {n: torch.empty_like(t) for n, t in zip(_TFM_ORDER, params) if n not in ("wq", "wk", "wv", "bq", "bk", "bv")}
+        grads.update(wq=gqkv_w[0], wk=gqkv_w[1], wv=gqkv_w[2], bq=gqkv_b[0], bk=gqkv_b[1], bv=gqkv_b[2])
+        G = TfmGrads(*[_p(grads[n]) for n in _TFM_ORDER])
+        dx = torch.empty(N, S, D, dtype=torch.float32, device=g.device)
+        L = lib()
+        ws = _ws(L.nr_tfm_layer_bwd_bf16_ws_bytes(N, S, D), g.device)
+        check(L.nr_tfm_layer_bwd_bf16(_p(g), _p(mask), N, S, D, H, C.byref(W), p, seed, site, mask_mode, C.byref(SV), C.byref(G), _p(dx),
+                                      _p(ws), ws.numel() * 4, _stream()), "nr_tfm_layer_bwd_bf16")
+        return (dx, None, None, None, None, None, None) + tuple(grads[n] for n in _TFM_ORDER)
+
+
+def _contiguous3(a, b, c):
+    n = a.numel() * a.element_size()
+    return b.data_ptr() == a.data_ptr() + n and c.data_ptr() == b.data_ptr() + n
+
+
+def tfm_layer_bf16_supported(S, D, H):
+    return D % 64 == 0 and D % H == 0 and S <= 32 and D // H <= 64
+
+
 def tfm_layer(x, mask, head_num, params, p_drop=0.0, seed=0, site=0, hf_mask=False, plan=None):
     """TFMLayer.forward (attention.py:173-182).  x [N,S,D] fp32, mask [N,S] int64 (1 = real),
     params: dict with keys wq,bq,wk,bk,wv,bv,wo,bo,ln1_g,ln1_b,w1,b1,w2,b2,ln2_g,ln2_b.
@@ -438,6 +495,10 @@ def tfm_layer(x, mask, head_num, params, p_drop=0.0, seed=0, site=0, hf_mask=Fal
         want = {"w1": (4 * D, D), "b1": (4 * D,), "w2": (D, 4 * D)}.get(n, (D, D) if n.startswith("w") else (D,))
         if tuple(t.shape) != want:
             raise NewsrecError(f"tfm_layer: parameter {n} has shape {tuple(t.shape)}, expected {want}")
+    if (plan is None and get_gemm_compute() == "bf16" and tfm_layer_bf16_supported(x.shape[1], D, int(head_num)) and x.shape[0] * x.shape[1] >= 128
+            and _contiguous3(plist[0], plist[2], plist[4]) and _contiguous3(plist[1], plist[3], plist[5])):
+        # the bf16 build proper: activations / attention tensors bf16 in HBM (BERT-sized layers, parity bar 1e-2)
+        return _TFMLayerBf16.apply(x, mask, int(head_num), float(p_drop), int(seed), int(site), 1 if hf_mask else 0, *plist)
     return _TFMLayer.apply(x, mask, int(head_num), float(p_drop), int(seed), int(site), 1 if hf_mask else 0, plan, *plist)
 
 
