@@ -239,10 +239,22 @@ typedef struct {
     float *s1, *y1, *s2;                                /* f32 [R,D]: drop(dense)+x, LN1 output (forward only), drop(dense)+y1 */
     float *stats, *row_max, *row_sum;                   /* [4,R], [N,H,S], [N,H,S] */
     uint16_t *w_h;                                      /* bf16 wqkv | wo | w1 | w2: 12 D^2 elements */
+    uint16_t *aT_h;                                     /* bf16 [4D, Rp], Rp = R rounded up to 64: the GELU output transposed (may be NULL:
+                                                           the backward then transposes a_h itself) */
 } nr_tfm_saved_bf16;
-int nr_tfm_layer_fwd_bf16(const float* x, const int64_t* mask, int64_t N, int64_t S, int64_t D, int64_t H, const nr_tfm_weights* w, float p_drop, uint64_t seed, uint32_t site_base, int mask_mode, nr_tfm_saved_bf16* saved, float* y, void* stream);
-size_t nr_tfm_layer_bwd_bf16_ws_bytes(int64_t N, int64_t S, int64_t D);
-int nr_tfm_layer_bwd_bf16(const float* dy, const int64_t* mask, int64_t N, int64_t S, int64_t D, int64_t H, const nr_tfm_weights* w, float p_drop, uint64_t seed, uint32_t site_base, int mask_mode, const nr_tfm_saved_bf16* saved, nr_tfm_grads* grads, float* dx, void* ws, size_t ws_bytes, void* stream);
+/* offs / row_map: NULL for the dense [N,S,D] layout (R = N*S), or the packed-title-token plan of nr_pack_plan / nr_pack_ids (R rows). */
+int nr_tfm_layer_fwd_bf16(const float* x, const int64_t* mask, const int32_t* offs, const int32_t* row_map, int64_t N, int64_t S, int64_t R, int64_t D, int64_t H, const nr_tfm_weights* w, float p_drop, uint64_t seed, uint32_t site_base, int mask_mode, nr_tfm_saved_bf16* saved, float* y, void* stream);
+size_t nr_tfm_layer_bwd_bf16_ws_bytes(int64_t R, int64_t D);
+int nr_tfm_layer_bwd_bf16(const float* dy, const int64_t* mask, const int32_t* offs, const int32_t* row_map, int64_t N, int64_t S, int64_t R, int64_t D, int64_t H, const nr_tfm_weights* w, float p_drop, uint64_t seed, uint32_t site_base, int mask_mode, const nr_tfm_saved_bf16* saved, nr_tfm_grads* grads, float* dx, void* ws, size_t ws_bytes, void* stream);
+
+/* packed-row variants of the BERT embedding stage pieces (HF BertEmbeddings behind AllBertNewsEncoder, encoder.py:65,74):
+ * the LayerNorm pair with the Philox element index AND the position row (x_period) taken from the ORIGINAL row
+ * row_map[r]; the embedding dropout likewise; nr_unpack_rows_f32 scatters packed rows back into a zeroed padded
+ * [Rfull, D] tensor (the position-row gradient sums over titles per position). */
+int nr_add_layernorm_packed_fwd_f32(const float* h, const float* x, int64_t x_period, const int32_t* row_map, const float* gamma, const float* beta, int64_t R, int64_t D, float eps, float p_drop, uint64_t seed, uint32_t site, float* y, float* s_out, float* mean, float* rstd, void* stream);
+int nr_add_layernorm_packed_bwd_f32(const float* dy, const float* s, const float* mean, const float* rstd, const float* gamma, const int32_t* row_map, int64_t R, int64_t D, float p_drop, uint64_t seed, uint32_t site, float* ds, float* dh, float* dgamma, float* dbeta, void* ws, size_t ws_bytes, void* stream);
+int nr_dropout_packed_f32(const float* x, const int32_t* row_map, int64_t R, int64_t D, float p_drop, uint64_t seed, uint32_t site, float* out, void* stream);
+int nr_unpack_rows_f32(const float* src, const int32_t* row_map, int64_t R, int64_t D, int64_t Rfull, float* dst, void* stream);
 
 /* ---- GRU user encoder — RnnUserEncoder, models/modules/encoder.py:204-233 -----------------------------
  * One-layer nn.GRU(Din, H, batch_first) over x [B,L,Din], packed by len_b = sum_l mask[b,l] (>= 1: the

@@ -1,5 +1,5 @@
 // Multi-head self-attention for title-length sequences (S <= 32, dh <= 64) on the f32 matrix cores.
-// One 256-thread workgroup per (sequence, group of 4 heads); one wave per head; a head is one 32x32
+// One workgroup per (sequence, group of NHG heads: 4 at head dim <= 32, 2 above — half the LDS, twice the workgroups per CU); one wave per head; a head is one 32x32
 // score tile.
 //
 // Orientation trick (v_mfma_f32_32x32x2_f32: lane l feeds A[i=l&31][k=l>>5], B[k=l>>5][j=l&31];
@@ -43,14 +43,14 @@ __device__ __forceinline__ void tile_zero_pad(float* tile, int S, int dh, int la
 
 // [S rows] x [nh*dh] global segment (row stride ld) -> nh per-head tiles [32][LD]
 template <int DHP>
-__device__ __forceinline__ void heads_in(float* tiles, const float* __restrict__ g, int64_t ld, int S, int dh, int nh, int tid, bool vec) {
+__device__ __forceinline__ void heads_in(float* tiles, const float* __restrict__ g, int64_t ld, int S, int dh, int nh, int tid, bool vec, int nthr = 256) {
     constexpr int LD = DHP + 1, TS = 32 * LD;
     const int W = nh * dh;
     const int inv_dh = (1048576 + dh - 1) / dh;
     if (vec) {
         const int nq = W >> 2;
         const int inv_nq = (1048576 + nq - 1) / nq;
-        for (int idx = tid; idx < S * nq; idx += 256) {
+        for (int idx = tid; idx < S * nq; idx += nthr) {
             const int r = fastdiv(idx, inv_nq);
             const int c = (idx - r * nq) << 2;
             const float4 v = *reinterpret_cast<const float4*>(g + (int64_t)r * ld + c);
@@ -63,7 +63,7 @@ __device__ __forceinline__ void heads_in(float* tiles, const float* __restrict__
             }
         }
     } else {
-        for (int idx = tid; idx < S * W; idx += 256) {
+        for (int idx = tid; idx < S * W; idx += nthr) {
             const int r = idx / W;
             const int c = idx - r * W;
             const int hh = fastdiv(c, inv_dh);
@@ -74,13 +74,13 @@ __device__ __forceinline__ void heads_in(float* tiles, const float* __restrict__
 // the same for a bf16 tensor (the bf16 build keeps qkv / ctx and their gradients as bf16 in HBM; the tiles and all the
 // arithmetic stay f32): 16-byte pieces of 8 elements when the segment allows it
 template <int DHP>
-__device__ __forceinline__ void heads_in(float* tiles, const unsigned short* __restrict__ g, int64_t ld, int S, int dh, int nh, int tid, bool vec) {
+__device__ __forceinline__ void heads_in(float* tiles, const unsigned short* __restrict__ g, int64_t ld, int S, int dh, int nh, int tid, bool vec, int nthr = 256) {
     constexpr int LD = DHP + 1, TS = 32 * LD;
     const int W = nh * dh;
     const int inv_dh = (1048576 + dh - 1) / dh;
     if (vec && (W & 7) == 0) {
         const int nq = W >> 3;
-        for (int idx = tid; idx < S * nq; idx += 256) {
+        for (int idx = tid; idx < S * nq; idx += nthr) {
             const int r = idx / nq;
             const int c = (idx - r * nq) << 3;
             const uint4 u = *reinterpret_cast<const uint4*>(g + (int64_t)r * ld + c);
@@ -94,7 +94,7 @@ __device__ __forceinline__ void heads_in(float* tiles, const unsigned short* __r
             }
         }
     } else {
-        for (int idx = tid; idx < S * W; idx += 256) {
+        for (int idx = tid; idx < S * W; idx += nthr) {
             const int r = idx / W;
             const int c = idx - r * W;
             const int hh = fastdiv(c, inv_dh);
@@ -109,13 +109,13 @@ __device__ __forceinline__ uint32_t apack2(float lo, float hi) {
     return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, abf16x2));
 }
 template <int DHP>
-__device__ __forceinline__ void heads_out(unsigned short* __restrict__ g, int64_t ld, const float* tiles, int S, int dh, int nh, int tid, bool vec) {
+__device__ __forceinline__ void heads_out(unsigned short* __restrict__ g, int64_t ld, const float* tiles, int S, int dh, int nh, int tid, bool vec, int nthr = 256) {
     constexpr int LD = DHP + 1, TS = 32 * LD;
     const int W = nh * dh;
     const int inv_dh = (1048576 + dh - 1) / dh;
     if (vec && (W & 7) == 0) {
         const int nq = W >> 3;
-        for (int idx = tid; idx < S * nq; idx += 256) {
+        for (int idx = tid; idx < S * nq; idx += nthr) {
             const int r = idx / nq;
             const int c = (idx - r * nq) << 3;
             int hh = fastdiv(c, inv_dh), d = c - hh * dh;
@@ -128,7 +128,7 @@ __device__ __forceinline__ void heads_out(unsigned short* __restrict__ g, int64_
             *reinterpret_cast<uint4*>(g + (int64_t)r * ld + c) = make_uint4(apack2(e[0], e[1]), apack2(e[2], e[3]), apack2(e[4], e[5]), apack2(e[6], e[7]));
         }
     } else {
-        for (int idx = tid; idx < S * W; idx += 256) {
+        for (int idx = tid; idx < S * W; idx += nthr) {
             const int r = idx / W;
             const int c = idx - r * W;
             const int hh = fastdiv(c, inv_dh);
@@ -138,14 +138,14 @@ __device__ __forceinline__ void heads_out(unsigned short* __restrict__ g, int64_
 }
 
 template <int DHP>
-__device__ __forceinline__ void heads_out(float* __restrict__ g, int64_t ld, const float* tiles, int S, int dh, int nh, int tid, bool vec) {
+__device__ __forceinline__ void heads_out(float* __restrict__ g, int64_t ld, const float* tiles, int S, int dh, int nh, int tid, bool vec, int nthr = 256) {
     constexpr int LD = DHP + 1, TS = 32 * LD;
     const int W = nh * dh;
     const int inv_dh = (1048576 + dh - 1) / dh;
     if (vec) {
         const int nq = W >> 2;
         const int inv_nq = (1048576 + nq - 1) / nq;
-        for (int idx = tid; idx < S * nq; idx += 256) {
+        for (int idx = tid; idx < S * nq; idx += nthr) {
             const int r = fastdiv(idx, inv_nq);
             const int c = (idx - r * nq) << 2;
             int hh = fastdiv(c, inv_dh), d = c - hh * dh;
@@ -158,7 +158,7 @@ __device__ __forceinline__ void heads_out(float* __restrict__ g, int64_t ld, con
             *reinterpret_cast<float4*>(g + (int64_t)r * ld + c) = make_float4(e[0], e[1], e[2], e[3]);
         }
     } else {
-        for (int idx = tid; idx < S * W; idx += 256) {
+        for (int idx = tid; idx < S * W; idx += nthr) {
             const int r = idx / W;
             const int c = idx - r * W;
             const int hh = fastdiv(c, inv_dh);
@@ -229,21 +229,21 @@ __device__ __forceinline__ unsigned keep_bits16(const DropoutCfg& dc, uint32_t t
     return bits;
 }
 
-template <int DHP, typename T>
-__global__ __launch_bounds__(256) void mhsa_fwd_mfma_kernel(const T* __restrict__ qkv, const int64_t* __restrict__ mask,
+template <int DHP, typename T, int NHG>
+__global__ __launch_bounds__(64 * NHG) void mhsa_fwd_mfma_kernel(const T* __restrict__ qkv, const int64_t* __restrict__ mask,
                                                             T* __restrict__ ctx, float* __restrict__ row_max,
                                                             float* __restrict__ row_sum, int S, int H, int dh, DropoutCfg dc,
                                                             int vec) {
     constexpr int LD = DHP + 1, TS = 32 * LD;
     constexpr int DT = DHP / 32;
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* Qt = smem;                  // [HPG][TS]  (reused for the output tiles)
-    float* Kt = Qt + HPG * TS;
-    float* Vt = Kt + HPG * TS;
+    float* Qt = smem;                  // [NHG][TS]  (reused for the output tiles)
+    float* Kt = Qt + NHG * TS;
+    float* Vt = Kt + NHG * TS;
     const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63, l31 = lane & 31, h = lane >> 5;
-    const int groups = (H + HPG - 1) / HPG;
+    const int groups = (H + NHG - 1) / NHG;
     const int n = blockIdx.x / groups, gidx = blockIdx.x - n * groups;
-    const int hd0 = gidx * HPG, nh = min(HPG, H - hd0), hd = hd0 + w;
+    const int hd0 = gidx * NHG, nh = min(NHG, H - hd0), hd = hd0 + w;
     const bool active = w < nh;
     const int A = H * dh;
     const int64_t ld = 3 * (int64_t)A;
@@ -253,9 +253,9 @@ __global__ __launch_bounds__(256) void mhsa_fwd_mfma_kernel(const T* __restrict_
     const int Sn = dc.offs ? dc.offs[n + 1] - dc.offs[n] : S;
     if (Sn == 0) return;                                        // a title with no rows (block-uniform)
     const T* base = qkv + row0 * ld + hd0 * dh;
-    heads_in<DHP>(Qt, base, ld, Sn, dh, nh, tid, vec);
-    heads_in<DHP>(Kt, base + A, ld, Sn, dh, nh, tid, vec);
-    heads_in<DHP>(Vt, base + 2 * A, ld, Sn, dh, nh, tid, vec);
+    heads_in<DHP>(Qt, base, ld, Sn, dh, nh, tid, vec, 64 * NHG);
+    heads_in<DHP>(Kt, base + A, ld, Sn, dh, nh, tid, vec, 64 * NHG);
+    heads_in<DHP>(Vt, base + 2 * A, ld, Sn, dh, nh, tid, vec, 64 * NHG);
     float* Qs = Qt + w * TS; float* Ks = Kt + w * TS; float* Vs = Vt + w * TS;
     if (active) { tile_zero_pad<DHP>(Qs, Sn, dh, lane); tile_zero_pad<DHP>(Ks, Sn, dh, lane); tile_zero_pad<DHP>(Vs, Sn, dh, lane); }
     __syncthreads();
@@ -305,11 +305,11 @@ __global__ __launch_bounds__(256) void mhsa_fwd_mfma_kernel(const T* __restrict_
         }
     }
     __syncthreads();
-    heads_out<DHP>(ctx + row0 * A + hd0 * dh, A, Qt, Sn, dh, nh, tid, vec);
+    heads_out<DHP>(ctx + row0 * A + hd0 * dh, A, Qt, Sn, dh, nh, tid, vec, 64 * NHG);
 }
 
-template <int DHP, typename T>
-__global__ __launch_bounds__(256) void mhsa_bwd_mfma_kernel(const T* __restrict__ qkv, const int64_t* __restrict__ mask,
+template <int DHP, typename T, int NHG>
+__global__ __launch_bounds__(64 * NHG) void mhsa_bwd_mfma_kernel(const T* __restrict__ qkv, const int64_t* __restrict__ mask,
                                                             const T* __restrict__ dctx, const float* __restrict__ row_max,
                                                             const float* __restrict__ row_sum, T* __restrict__ dqkv,
                                                             int S, int H, int dh, DropoutCfg dc, int vec) {
@@ -317,14 +317,14 @@ __global__ __launch_bounds__(256) void mhsa_bwd_mfma_kernel(const T* __restrict_
     constexpr int DT = DHP / 32;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* Qt = smem;
-    float* Kt = Qt + HPG * TS;
-    float* Vt = Kt + HPG * TS;
-    float* Gt = Vt + HPG * TS;
-    float* St = Gt + HPG * TS;          // [HPG][4][32]: max, sum, D, key-mask term ; then [HPG][32] keep words
+    float* Kt = Qt + NHG * TS;
+    float* Vt = Kt + NHG * TS;
+    float* Gt = Vt + NHG * TS;
+    float* St = Gt + NHG * TS;          // [NHG][4][32]: max, sum, D, key-mask term ; then [NHG][32] keep words
     const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63, l31 = lane & 31, h = lane >> 5;
-    const int groups = (H + HPG - 1) / HPG;
+    const int groups = (H + NHG - 1) / NHG;
     const int n = blockIdx.x / groups, gidx = blockIdx.x - n * groups;
-    const int hd0 = gidx * HPG, nh = min(HPG, H - hd0), hd = hd0 + w;
+    const int hd0 = gidx * NHG, nh = min(NHG, H - hd0), hd = hd0 + w;
     const bool active = w < nh;
     const int A = H * dh;
     const int64_t ld = 3 * (int64_t)A;
@@ -332,13 +332,13 @@ __global__ __launch_bounds__(256) void mhsa_bwd_mfma_kernel(const T* __restrict_
     const int Sn = dc.offs ? dc.offs[n + 1] - dc.offs[n] : S;
     if (Sn == 0) return;
     const T* base = qkv + row0 * ld + hd0 * dh;
-    heads_in<DHP>(Qt, base, ld, Sn, dh, nh, tid, vec);
-    heads_in<DHP>(Kt, base + A, ld, Sn, dh, nh, tid, vec);
-    heads_in<DHP>(Vt, base + 2 * A, ld, Sn, dh, nh, tid, vec);
-    heads_in<DHP>(Gt, dctx + row0 * A + hd0 * dh, A, Sn, dh, nh, tid, vec);
+    heads_in<DHP>(Qt, base, ld, Sn, dh, nh, tid, vec, 64 * NHG);
+    heads_in<DHP>(Kt, base + A, ld, Sn, dh, nh, tid, vec, 64 * NHG);
+    heads_in<DHP>(Vt, base + 2 * A, ld, Sn, dh, nh, tid, vec, 64 * NHG);
+    heads_in<DHP>(Gt, dctx + row0 * A + hd0 * dh, A, Sn, dh, nh, tid, vec, 64 * NHG);
     float* Qs = Qt + w * TS; float* Ks = Kt + w * TS; float* Vs = Vt + w * TS; float* Gs = Gt + w * TS;
     float* Ms = St + w * 128; float* Ls = Ms + 32; float* Dsh = Ms + 64; float* Mk = Ms + 96;
-    unsigned* Kb = reinterpret_cast<unsigned*>(St + HPG * 128) + w * 32;
+    unsigned* Kb = reinterpret_cast<unsigned*>(St + NHG * 128) + w * 32;
     const int64_t qrow0 = ((int64_t)n * H + hd) * S;
     if (active) {
         tile_zero_pad<DHP>(Qs, Sn, dh, lane); tile_zero_pad<DHP>(Ks, Sn, dh, lane);
@@ -416,8 +416,8 @@ __global__ __launch_bounds__(256) void mhsa_bwd_mfma_kernel(const T* __restrict_
         }
     }
     __syncthreads();
-    heads_out<DHP>(dbase, ld, Kt, Sn, dh, nh, tid, vec);
-    heads_out<DHP>(dbase + A, ld, Vt, Sn, dh, nh, tid, vec);
+    heads_out<DHP>(dbase, ld, Kt, Sn, dh, nh, tid, vec, 64 * NHG);
+    heads_out<DHP>(dbase + A, ld, Vt, Sn, dh, nh, tid, vec, 64 * NHG);
     __syncthreads();
     if (active) {
 #pragma unroll
@@ -427,67 +427,67 @@ __global__ __launch_bounds__(256) void mhsa_bwd_mfma_kernel(const T* __restrict_
         }
     }
     __syncthreads();
-    heads_out<DHP>(dbase + 2 * A, ld, Kt, Sn, dh, nh, tid, vec);
+    heads_out<DHP>(dbase + 2 * A, ld, Kt, Sn, dh, nh, tid, vec, 64 * NHG);
 }
 
 bool mhsa_mfma_supported(int S, int dh) { return S >= 1 && S <= 32 && dh >= 1 && dh <= 64; }
 
-static bool vec_ok(const void* a, const void* b, int H, int dh) {
+static bool vec_ok(const void* a, const void* b, int H, int dh, int hpg = HPG) {
     // 16-byte segments: 4 heads start on a 16-B boundary iff the row pitch and the q/k/v offsets do
     const int A = H * dh;
     return (A % 4 == 0) && (((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b)) & 15) == 0) &&
-           (H % HPG == 0 || (dh % 4 == 0));
+           (H % hpg == 0 || (dh % 4 == 0));
 }
 
 template <typename T>
 static int launch_fwd(const T* qkv, const int64_t* mask, T* ctx, float* row_max, float* row_sum, int64_t N, int S, int H, int dh, DropoutCfg dc,
                       int vec, hipStream_t s) {
-    const int groups = (H + HPG - 1) / HPG;
-    const dim3 grid((unsigned)(N * groups));
     const int dhp = dh <= 32 ? 32 : 64;
-    const size_t lds = (size_t)3 * HPG * 32 * (dhp + 1) * sizeof(float);
+    const int hpg = dhp == 32 ? 4 : 2;
+    const dim3 grid((unsigned)(N * ((H + hpg - 1) / hpg)));
+    const size_t lds = (size_t)3 * hpg * 32 * (dhp + 1) * sizeof(float);
     if (dhp == 32) {
-        hipLaunchKernelGGL((mhsa_fwd_mfma_kernel<32, T>), grid, dim3(256), lds, s, qkv, mask, ctx, row_max, row_sum, S, H, dh, dc, vec);
+        hipLaunchKernelGGL((mhsa_fwd_mfma_kernel<32, T, 4>), grid, dim3(256), lds, s, qkv, mask, ctx, row_max, row_sum, S, H, dh, dc, vec);
     } else {
         static bool once = false;
-        if (!once) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mhsa_fwd_mfma_kernel<64, T>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); once = true; }
-        hipLaunchKernelGGL((mhsa_fwd_mfma_kernel<64, T>), grid, dim3(256), lds, s, qkv, mask, ctx, row_max, row_sum, S, H, dh, dc, vec);
+        if (!once) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mhsa_fwd_mfma_kernel<64, T, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); once = true; }
+        hipLaunchKernelGGL((mhsa_fwd_mfma_kernel<64, T, 2>), grid, dim3(128), lds, s, qkv, mask, ctx, row_max, row_sum, S, H, dh, dc, vec);
     }
     return check_launch("mhsa_fwd_mfma");
 }
 template <typename T>
 static int launch_bwd(const T* qkv, const int64_t* mask, const T* dctx, const float* row_max, const float* row_sum, T* dqkv, int64_t N, int S,
                       int H, int dh, DropoutCfg dc, int vec, hipStream_t s) {
-    const int groups = (H + HPG - 1) / HPG;
-    const dim3 grid((unsigned)(N * groups));
     const int dhp = dh <= 32 ? 32 : 64;
-    const size_t lds = ((size_t)4 * HPG * 32 * (dhp + 1) + HPG * 128 + HPG * 32) * sizeof(float);
+    const int hpg = dhp == 32 ? 4 : 2;
+    const dim3 grid((unsigned)(N * ((H + hpg - 1) / hpg)));
+    const size_t lds = ((size_t)4 * hpg * 32 * (dhp + 1) + hpg * 128 + hpg * 32) * sizeof(float);
     if (dhp == 32) {
         static bool once = false;
-        if (!once) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mhsa_bwd_mfma_kernel<32, T>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); once = true; }
-        hipLaunchKernelGGL((mhsa_bwd_mfma_kernel<32, T>), grid, dim3(256), lds, s, qkv, mask, dctx, row_max, row_sum, dqkv, S, H, dh, dc, vec);
+        if (!once) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mhsa_bwd_mfma_kernel<32, T, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); once = true; }
+        hipLaunchKernelGGL((mhsa_bwd_mfma_kernel<32, T, 4>), grid, dim3(256), lds, s, qkv, mask, dctx, row_max, row_sum, dqkv, S, H, dh, dc, vec);
     } else {
         static bool once = false;
-        if (!once) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mhsa_bwd_mfma_kernel<64, T>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); once = true; }
-        hipLaunchKernelGGL((mhsa_bwd_mfma_kernel<64, T>), grid, dim3(256), lds, s, qkv, mask, dctx, row_max, row_sum, dqkv, S, H, dh, dc, vec);
+        if (!once) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mhsa_bwd_mfma_kernel<64, T, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); once = true; }
+        hipLaunchKernelGGL((mhsa_bwd_mfma_kernel<64, T, 2>), grid, dim3(128), lds, s, qkv, mask, dctx, row_max, row_sum, dqkv, S, H, dh, dc, vec);
     }
     return check_launch("mhsa_bwd_mfma");
 }
 
 int mhsa_fwd_mfma(const float* qkv, const int64_t* mask, float* ctx, float* row_max, float* row_sum, int64_t N, int S, int H,
                   int dh, DropoutCfg dc, hipStream_t s) {
-    return launch_fwd<float>(qkv, mask, ctx, row_max, row_sum, N, S, H, dh, dc, vec_ok(qkv, ctx, H, dh) ? 1 : 0, s);
+    return launch_fwd<float>(qkv, mask, ctx, row_max, row_sum, N, S, H, dh, dc, vec_ok(qkv, ctx, H, dh, dh <= 32 ? 4 : 2) ? 1 : 0, s);
 }
 
 int mhsa_bwd_mfma(const float* qkv, const int64_t* mask, const float* dctx, const float* row_max, const float* row_sum,
                   float* dqkv, int64_t N, int S, int H, int dh, DropoutCfg dc, hipStream_t s) {
-    return launch_bwd<float>(qkv, mask, dctx, row_max, row_sum, dqkv, N, S, H, dh, dc, (vec_ok(qkv, dctx, H, dh) && vec_ok(dqkv, dqkv, H, dh)) ? 1 : 0, s);
+    return launch_bwd<float>(qkv, mask, dctx, row_max, row_sum, dqkv, N, S, H, dh, dc, (vec_ok(qkv, dctx, H, dh, dh <= 32 ? 4 : 2) && vec_ok(dqkv, dqkv, H, dh, dh <= 32 ? 4 : 2)) ? 1 : 0, s);
 }
 
 // bf16 tensors in HBM (raw 16-bit storage), f32 tiles and arithmetic; 16-byte pieces need A % 8 == 0 and aligned bases
 static bool vec_ok_h(const void* a, const void* b, int H, int dh) {
     const int A = H * dh;
-    return (A % 8 == 0) && (((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b)) & 15) == 0) && ((HPG * dh) % 8 == 0);
+    return (A % 8 == 0) && (((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b)) & 15) == 0) && (((dh <= 32 ? 4 : 2) * dh) % 8 == 0);
 }
 int mhsa_fwd_mfma_h(const unsigned short* qkv, const int64_t* mask, unsigned short* ctx, float* row_max, float* row_sum, int64_t N, int S,
                     int H, int dh, DropoutCfg dc, hipStream_t s) {

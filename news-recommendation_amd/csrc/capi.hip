@@ -269,13 +269,14 @@ size_t nr_layernorm_bwd_ws_bytes(int64_t R, int64_t D) {
 }
 
 static int layernorm_bwd(const float* dy, const float* s_in, const float* mean, const float* rstd, const float* gamma, int64_t R,
-                         int D, DropoutCfg dc, float* ds, float* dh, float* dgamma, float* dbeta, char* ws, hipStream_t s) {
+                         int D, DropoutCfg dc, float* ds, float* dh, float* dgamma, float* dbeta, char* ws, hipStream_t s,
+                         unsigned short* dh_h = nullptr) {
     char* cur = ws;
     const int nb = ln_bwd_blocks(R);
     float* pg = bump(cur, (size_t)nb * D);
     float* pb = bump(cur, (size_t)nb * D);
     float* part = bump(cur, (size_t)2 * colsum_chunks(nb) * D);
-    if (int rc = ln_bwd(dy, s_in, mean, rstd, gamma, ds, dh, pg, pb, R, D, dc, s)) return rc;
+    if (int rc = ln_bwd(dy, s_in, mean, rstd, gamma, ds, dh, pg, pb, R, D, dc, s, dh_h)) return rc;
     return colsum2(pg, pb, nb, D, dgamma, dbeta, part, s);       // dgamma and dbeta in one launch pair
 }
 
@@ -284,6 +285,31 @@ int nr_add_layernorm_bwd_f32(const float* dy, const float* s_in, const float* me
     NR_CHECK_ARG(dy && s_in && mean && rstd && gamma && ds && dgamma && dbeta, "layernorm_bwd: null pointer");
     if (!ws || ws_bytes < nr_layernorm_bwd_ws_bytes(R, D)) { set_error("layernorm_bwd: workspace too small"); return NR_ERR_WORKSPACE; }
     return layernorm_bwd(dy, s_in, mean, rstd, gamma, R, (int)D, DC(p_drop, seed, site), ds, dh, dgamma, dbeta, (char*)ws, S(stream));
+}
+
+int nr_add_layernorm_packed_fwd_f32(const float* h, const float* x, int64_t x_period, const int32_t* row_map, const float* gamma, const float* beta, int64_t R, int64_t D, float eps, float p_drop, uint64_t seed, uint32_t site, float* y, float* s_out, float* mean, float* rstd, void* stream) {
+    NR_CHECK_ARG(R >= 0 && D > 0 && x_period >= 0, "layernorm_packed_fwd: bad sizes");
+    NR_CHECK_ARG(R == 0 || (h && gamma && beta && y && row_map), "layernorm_packed_fwd: null pointer");
+    NR_CHECK_ARG(p_drop >= 0.f && p_drop < 1.f, "layernorm_packed_fwd: p_drop %f not in [0,1)", p_drop);
+    return ln_fwd(h, x, gamma, beta, y, s_out, mean, rstd, R, (int)D, eps, DCP(DC(p_drop, seed, site), nullptr, row_map), S(stream), x_period);
+}
+
+int nr_add_layernorm_packed_bwd_f32(const float* dy, const float* s_in, const float* mean, const float* rstd, const float* gamma, const int32_t* row_map, int64_t R, int64_t D, float p_drop, uint64_t seed, uint32_t site, float* ds, float* dh, float* dgamma, float* dbeta, void* ws, size_t ws_bytes, void* stream) {
+    NR_CHECK_ARG(R > 0 && D > 0, "layernorm_packed_bwd: bad sizes");
+    NR_CHECK_ARG(dy && s_in && mean && rstd && gamma && ds && dgamma && dbeta && row_map, "layernorm_packed_bwd: null pointer");
+    if (!ws || ws_bytes < nr_layernorm_bwd_ws_bytes(R, D)) { set_error("layernorm_packed_bwd: workspace too small"); return NR_ERR_WORKSPACE; }
+    return layernorm_bwd(dy, s_in, mean, rstd, gamma, R, (int)D, DCP(DC(p_drop, seed, site), nullptr, row_map), ds, dh, dgamma, dbeta, (char*)ws, S(stream));
+}
+
+int nr_dropout_packed_f32(const float* x, const int32_t* row_map, int64_t R, int64_t D, float p_drop, uint64_t seed, uint32_t site, float* out, void* stream) {
+    NR_CHECK_ARG(R >= 0 && D > 0 && (R == 0 || (x && out && row_map)), "dropout_packed: bad arguments");
+    NR_CHECK_ARG(p_drop > 0.f && p_drop < 1.f, "dropout_packed: p_drop %f not in (0,1)", p_drop);
+    return dropout_f32(x, out, R * D, DCP(DC(p_drop, seed, site), nullptr, row_map), S(stream), (int)D);
+}
+
+int nr_unpack_rows_f32(const float* src, const int32_t* row_map, int64_t R, int64_t D, int64_t Rfull, float* dst, void* stream) {
+    NR_CHECK_ARG(R >= 0 && D > 0 && Rfull >= 0 && dst && (R == 0 || (src && row_map)), "unpack_rows: bad arguments");
+    return unpack_rows(src, row_map, R, (int)D, Rfull, dst, S(stream));
 }
 
 // ---- the one entry point that allocates nothing (callers that cannot hipMalloc) ---------------------------------
@@ -657,8 +683,10 @@ static bool tfm_bf16_supported(int64_t Sq, int64_t D, int64_t H) {
     return D % 64 == 0 && H > 0 && D % H == 0 && mhsa_mfma_supported((int)Sq, (int)(D / H));
 }
 static int gemm_nt(const unsigned short* A, int64_t lda, const unsigned short* B, int64_t ldb, int64_t M, int64_t N, int64_t K, const float* bias, int epi,
-                   float* C, unsigned short* Ch, const float* aux, const unsigned short* auxh, unsigned short* out2h, hipStream_t s) {
+                   float* C, unsigned short* Ch, const float* aux, const unsigned short* auxh, unsigned short* out2h, hipStream_t s,
+                   unsigned short* ChT = nullptr, int64_t ldcht = 0) {
     GemmHParams p;
+    p.ChT = ChT; p.ldcht = ldcht;
     p.A = A; p.lda = lda; p.B = B; p.ldb = ldb; p.M = (int)M; p.N = (int)N; p.K = (int)K;
     p.C = C; p.ldc = N; p.Ch = Ch; p.ldch = N; p.bias = bias; p.epi = epi;
     p.aux = aux; p.ldaux = N; p.auxh = auxh; p.ldauxh = N; p.out2h = out2h; p.ldout2h = N;
@@ -673,17 +701,17 @@ static int gemm_dw(const unsigned short* dyT, const unsigned short* xT, int64_t 
     return gemm_h(p, ws, ws_bytes, s);
 }
 
-int nr_tfm_layer_fwd_bf16(const float* x, const int64_t* mask, int64_t N, int64_t Sq, int64_t D, int64_t H, const nr_tfm_weights* w, float p_drop, uint64_t seed, uint32_t site_base, int mask_mode, nr_tfm_saved_bf16* sv, float* y, void* stream) {
-    NR_CHECK_ARG(N >= 0 && Sq > 0 && D > 0 && H > 0, "tfm_layer_fwd_bf16: bad sizes");
+int nr_tfm_layer_fwd_bf16(const float* x, const int64_t* mask, const int32_t* offs, const int32_t* row_map, int64_t N, int64_t Sq, int64_t R, int64_t D, int64_t H, const nr_tfm_weights* w, float p_drop, uint64_t seed, uint32_t site_base, int mask_mode, nr_tfm_saved_bf16* sv, float* y, void* stream) {
+    NR_CHECK_ARG(N >= 0 && Sq > 0 && D > 0 && H > 0 && R >= 0 && R <= N * Sq, "tfm_layer_fwd_bf16: bad sizes");
+    NR_CHECK_ARG((offs == nullptr) == (row_map == nullptr) && (offs || R == N * Sq), "tfm_layer_fwd_bf16: packed rows need offs and row_map; dense rows R = N*S");
     NR_CHECK_ARG(w && sv && x && mask && y, "tfm_layer_fwd_bf16: null pointer");
     NR_UNSUPPORTED(!tfm_bf16_supported(Sq, D, H), "tfm_layer_fwd_bf16: needs D %% 64 == 0, S <= 32, head dim <= 64 (got S=%lld D=%lld H=%lld)", (long long)Sq, (long long)D, (long long)H);
     NR_CHECK_ARG(sv->x_h && sv->qkv_h && sv->ctx_h && sv->y1_h && sv->a_h && sv->s1 && sv->y1 && sv->s2 && sv->w_h, "tfm_layer_fwd_bf16: missing buffer");
     NR_CHECK_ARG(p_drop >= 0.f && p_drop < 1.f, "tfm_layer_fwd_bf16: p_drop %f not in [0,1)", p_drop);
     const size_t DD = (size_t)D * D;
     NR_CHECK_ARG(contiguous3(w->wq, w->wk, w->wv, DD) && contiguous3(w->bq, w->bk, w->bv, (size_t)D), "tfm_layer_fwd_bf16: q|k|v weights and biases must be contiguous (packed [3D, D])");
-    if (N == 0) return NR_OK;
+    if (N == 0 || R == 0) return NR_OK;
     hipStream_t s = S(stream);
-    const int64_t R = N * Sq;
     unsigned short* wqkv_h = sv->w_h, *wo_h = wqkv_h + 3 * DD, *w1_h = wo_h + DD, *w2_h = w1_h + 4 * DD;
     if (int rc = cast_bf16(w->wq, wqkv_h, 3 * DD, s)) return rc;
     if (int rc = cast_bf16(w->wo, wo_h, DD, s)) return rc;
@@ -695,19 +723,19 @@ int nr_tfm_layer_fwd_bf16(const float* x, const int64_t* mask, int64_t N, int64_
     float* mean2 = sv->stats ? sv->stats + 2 * R : nullptr;
     float* rstd2 = sv->stats ? sv->stats + 3 * R : nullptr;
     if (int rc = gemm_nt(sv->x_h, D, wqkv_h, D, R, 3 * D, D, w->bq, EPI_NONE, nullptr, sv->qkv_h, nullptr, nullptr, nullptr, s)) return rc;
-    if (int rc = mhsa_fwd_mfma_h(sv->qkv_h, mask, sv->ctx_h, sv->row_max, sv->row_sum, N, (int)Sq, (int)H, (int)(D / H), DCA(p_drop, seed, site_base, mask_mode), s)) return rc;
+    if (int rc = mhsa_fwd_mfma_h(sv->qkv_h, mask, sv->ctx_h, sv->row_max, sv->row_sum, N, (int)Sq, (int)H, (int)(D / H), DCP(DCA(p_drop, seed, site_base, mask_mode), offs, nullptr), s)) return rc;
     if (int rc = gemm_nt(sv->ctx_h, D, wo_h, D, R, D, D, w->bo, EPI_NONE, sv->s1, nullptr, nullptr, nullptr, nullptr, s)) return rc;
-    if (int rc = ln_fwd(sv->s1, x, w->ln1_g, w->ln1_b, sv->y1, sv->s1, mean1, rstd1, R, (int)D, 1e-12f, DC(p_drop, seed, site_base + 1), s)) return rc;
-    if (int rc = cast_bf16(sv->y1, sv->y1_h, R * D, s)) return rc;
-    if (int rc = gemm_nt(sv->y1_h, D, w1_h, D, R, 4 * D, D, w->b1, EPI_GELU, nullptr, sv->a_h, nullptr, nullptr, sv->z_h, s)) return rc;
+    if (int rc = ln_fwd(sv->s1, x, w->ln1_g, w->ln1_b, sv->y1, sv->s1, mean1, rstd1, R, (int)D, 1e-12f, DCP(DC(p_drop, seed, site_base + 1), nullptr, row_map), s, 0, sv->y1_h)) return rc;
+    // (the GELU output also leaves transposed, [4D, Rp]: the dW2 product of the backward takes it as is)
+    if (int rc = gemm_nt(sv->y1_h, D, w1_h, D, R, 4 * D, D, w->b1, EPI_GELU, nullptr, sv->a_h, nullptr, nullptr, sv->z_h, s, sv->aT_h, sv->aT_h ? (R + 63) / 64 * 64 : 0)) return rc;
     if (int rc = gemm_nt(sv->a_h, 4 * D, w2_h, 4 * D, R, D, 4 * D, w->b2, EPI_NONE, sv->s2, nullptr, nullptr, nullptr, nullptr, s)) return rc;
-    return ln_fwd(sv->s2, sv->y1, w->ln2_g, w->ln2_b, y, sv->s2, mean2, rstd2, R, (int)D, 1e-12f, DC(p_drop, seed, site_base + 2), s);
+    return ln_fwd(sv->s2, sv->y1, w->ln2_g, w->ln2_b, y, sv->s2, mean2, rstd2, R, (int)D, 1e-12f, DCP(DC(p_drop, seed, site_base + 2), nullptr, row_map), s);
 }
 
 static size_t dw_ws_h(int64_t N, int64_t K, int64_t Rp) { return pad256b(gemm_h_workspace_bytes((int)N, (int)K, choose_ksplit_h((int)N, (int)K, (int)Rp))); }
 
-size_t nr_tfm_layer_bwd_bf16_ws_bytes(int64_t N, int64_t Sq, int64_t D) {
-    const int64_t R = N * Sq, Rp = (R + 63) / 64 * 64;
+size_t nr_tfm_layer_bwd_bf16_ws_bytes(int64_t R, int64_t D) {
+    const int64_t Rp = (R + 63) / 64 * 64;
     size_t b = 0;
     b += 5 * pad256((size_t)R * D);                                        // ds2 dh2 dy1 ds1 dh1 (f32)
     b += 2 * pad256b((size_t)R * D * 2);                                   // dh_h, dctx_h
@@ -721,17 +749,18 @@ size_t nr_tfm_layer_bwd_bf16_ws_bytes(int64_t N, int64_t Sq, int64_t D) {
     return b + wmax + 256;
 }
 
-int nr_tfm_layer_bwd_bf16(const float* dy, const int64_t* mask, int64_t N, int64_t Sq, int64_t D, int64_t H, const nr_tfm_weights* w, float p_drop, uint64_t seed, uint32_t site_base, int mask_mode, const nr_tfm_saved_bf16* sv, nr_tfm_grads* g, float* dx, void* ws, size_t ws_bytes, void* stream) {
-    NR_CHECK_ARG(N > 0 && Sq > 0 && D > 0 && H > 0, "tfm_layer_bwd_bf16: bad sizes");
+int nr_tfm_layer_bwd_bf16(const float* dy, const int64_t* mask, const int32_t* offs, const int32_t* row_map, int64_t N, int64_t Sq, int64_t R, int64_t D, int64_t H, const nr_tfm_weights* w, float p_drop, uint64_t seed, uint32_t site_base, int mask_mode, const nr_tfm_saved_bf16* sv, nr_tfm_grads* g, float* dx, void* ws, size_t ws_bytes, void* stream) {
+    NR_CHECK_ARG(N > 0 && Sq > 0 && D > 0 && H > 0 && R > 0 && R <= N * Sq, "tfm_layer_bwd_bf16: bad sizes");
+    NR_CHECK_ARG((offs == nullptr) == (row_map == nullptr) && (offs || R == N * Sq), "tfm_layer_bwd_bf16: packed rows need offs and row_map; dense rows R = N*S");
     NR_CHECK_ARG(dy && mask && w && sv && g && dx, "tfm_layer_bwd_bf16: null pointer");
     NR_UNSUPPORTED(!tfm_bf16_supported(Sq, D, H), "tfm_layer_bwd_bf16: needs D %% 64 == 0, S <= 32, head dim <= 64");
     NR_CHECK_ARG(sv->x_h && sv->qkv_h && sv->ctx_h && sv->y1_h && sv->z_h && sv->a_h && sv->s1 && sv->s2 && sv->stats && sv->row_max && sv->row_sum, "tfm_layer_bwd_bf16: missing saved activation");
     const size_t DD = (size_t)D * D;
     NR_CHECK_ARG(contiguous3(w->wq, w->wk, w->wv, DD), "tfm_layer_bwd_bf16: q|k|v weights must be contiguous");
     NR_CHECK_ARG(contiguous3(g->dwq, g->dwk, g->dwv, DD) && contiguous3(g->dbq, g->dbk, g->dbv, (size_t)D), "tfm_layer_bwd_bf16: q|k|v gradients must be contiguous");
-    if (!ws || ws_bytes < nr_tfm_layer_bwd_bf16_ws_bytes(N, Sq, D)) { set_error("tfm_layer_bwd_bf16: workspace too small"); return NR_ERR_WORKSPACE; }
+    if (!ws || ws_bytes < nr_tfm_layer_bwd_bf16_ws_bytes(R, D)) { set_error("tfm_layer_bwd_bf16: workspace too small"); return NR_ERR_WORKSPACE; }
     hipStream_t s = S(stream);
-    const int64_t R = N * Sq, Rp = (R + 63) / 64 * 64;
+    const int64_t Rp = (R + 63) / 64 * 64;
     char* cur = (char*)ws;
     float* ds2 = bump(cur, (size_t)R * D);
     float* dh2 = p_drop > 0.f ? bump(cur, (size_t)R * D) : ds2;
@@ -753,26 +782,27 @@ int nr_tfm_layer_bwd_bf16(const float* dy, const int64_t* mask, int64_t N, int64
     const float* mean1 = sv->stats, *rstd1 = sv->stats + R, *mean2 = sv->stats + 2 * R, *rstd2 = sv->stats + 3 * R;
 
     // LN2 <- dy
-    if (int rc = layernorm_bwd(dy, sv->s2, mean2, rstd2, w->ln2_g, R, (int)D, DC(p_drop, seed, site_base + 2), ds2, p_drop > 0.f ? dh2 : nullptr, g->dln2_g, g->dln2_b, lnws, s)) return rc;
+    if (int rc = layernorm_bwd(dy, sv->s2, mean2, rstd2, w->ln2_g, R, (int)D, DCP(DC(p_drop, seed, site_base + 2), nullptr, row_map), ds2, p_drop > 0.f ? dh2 : nullptr, g->dln2_g, g->dln2_b, lnws, s, dh_h)) return rc;
     // FFN2: dW2 [D,4D] = dh2^T a ; db2 ; dz = (dh2 W2) * gelu'(z)
-    if (int rc = cast_bf16(dh2, dh_h, R * D, s)) return rc;
     if (int rc = transpose_bf16(dh2, 0, D, R, D, dhT, Rp, s)) return rc;
-    if (int rc = transpose_bf16(sv->a_h, 1, 4 * D, R, 4 * D, actT, Rp, s)) return rc;
-    if (int rc = gemm_dw(dhT, actT, D, 4 * D, Rp, g->dw2, slabs, slab_bytes, s)) return rc;
+    const unsigned short* aT = sv->aT_h;
+    if (!aT) {
+        if (int rc = transpose_bf16(sv->a_h, 1, 4 * D, R, 4 * D, actT, Rp, s)) return rc;
+        aT = actT;
+    }
+    if (int rc = gemm_dw(dhT, aT, D, 4 * D, Rp, g->dw2, slabs, slab_bytes, s)) return rc;
     if (int rc = colsum(dh2, D, R, (int)D, g->db2, cpart, s)) return rc;
     if (int rc = transpose_bf16(w->w2, 0, 4 * D, D, 4 * D, wT, D, s)) return rc;                       // [D,4D] -> [4D,D]
-    if (int rc = gemm_nt(dh_h, D, wT, D, R, 4 * D, D, nullptr, EPI_MUL_GELU_GRAD, nullptr, dz_h, nullptr, sv->z_h, nullptr, s)) return rc;
-    // FFN1: dW1 [4D,D] = dz^T y1 ; db1 ; dy1 = dz W1 + ds2
-    if (int rc = transpose_bf16(dz_h, 1, 4 * D, R, 4 * D, dzT, Rp, s)) return rc;
+    if (int rc = gemm_nt(dh_h, D, wT, D, R, 4 * D, D, nullptr, EPI_MUL_GELU_GRAD, nullptr, dz_h, nullptr, sv->z_h, nullptr, s, dzT, Rp)) return rc;
+    // FFN1: dW1 [4D,D] = dz^T y1 ; db1 ; dy1 = dz W1 + ds2   (dz^T came out of the product above)
     if (int rc = transpose_bf16(sv->y1_h, 1, D, R, D, actT, Rp, s)) return rc;
     if (int rc = gemm_dw(dzT, actT, 4 * D, D, Rp, g->dw1, slabs, slab_bytes, s)) return rc;
     if (int rc = colsum_h(dz_h, 4 * D, R, (int)(4 * D), g->db1, cpart, s)) return rc;
     if (int rc = transpose_bf16(w->w1, 0, D, 4 * D, D, wT, 4 * D, s)) return rc;                       // [4D,D] -> [D,4D]
     if (int rc = gemm_nt(dz_h, 4 * D, wT, 4 * D, R, D, 4 * D, nullptr, EPI_ADD_AUX, dy1, nullptr, ds2, nullptr, nullptr, s)) return rc;
     // LN1
-    if (int rc = layernorm_bwd(dy1, sv->s1, mean1, rstd1, w->ln1_g, R, (int)D, DC(p_drop, seed, site_base + 1), ds1, p_drop > 0.f ? dh1 : nullptr, g->dln1_g, g->dln1_b, lnws, s)) return rc;
+    if (int rc = layernorm_bwd(dy1, sv->s1, mean1, rstd1, w->ln1_g, R, (int)D, DCP(DC(p_drop, seed, site_base + 1), nullptr, row_map), ds1, p_drop > 0.f ? dh1 : nullptr, g->dln1_g, g->dln1_b, lnws, s, dh_h)) return rc;
     // attention output projection: dWo = dh1^T ctx ; dbo ; dctx = dh1 Wo
-    if (int rc = cast_bf16(dh1, dh_h, R * D, s)) return rc;
     if (int rc = transpose_bf16(dh1, 0, D, R, D, dhT, Rp, s)) return rc;
     if (int rc = transpose_bf16(sv->ctx_h, 1, D, R, D, actT, Rp, s)) return rc;
     if (int rc = gemm_dw(dhT, actT, D, D, Rp, g->dwo, slabs, slab_bytes, s)) return rc;
@@ -780,7 +810,7 @@ int nr_tfm_layer_bwd_bf16(const float* dy, const int64_t* mask, int64_t N, int64
     if (int rc = transpose_bf16(w->wo, 0, D, D, D, wT, D, s)) return rc;
     if (int rc = gemm_nt(dh_h, D, wT, D, R, D, D, nullptr, EPI_NONE, nullptr, dctx_h, nullptr, nullptr, nullptr, s)) return rc;
     // attention core
-    if (int rc = mhsa_bwd_mfma_h(sv->qkv_h, mask, dctx_h, sv->row_max, sv->row_sum, dqkv_h, N, (int)Sq, (int)H, (int)(D / H), DCA(p_drop, seed, site_base, mask_mode), s)) return rc;
+    if (int rc = mhsa_bwd_mfma_h(sv->qkv_h, mask, dctx_h, sv->row_max, sv->row_sum, dqkv_h, N, (int)Sq, (int)H, (int)(D / H), DCP(DCA(p_drop, seed, site_base, mask_mode), offs, nullptr), s)) return rc;
     // QKV projection: dWqkv [3D,D] = dqkv^T x ; dbqkv ; dx = dqkv Wqkv + ds1
     if (int rc = transpose_bf16(dqkv_h, 1, 3 * D, R, 3 * D, dzT, Rp, s)) return rc;
     if (int rc = transpose_bf16(sv->x_h, 1, D, R, D, actT, Rp, s)) return rc;

@@ -49,6 +49,8 @@ struct GemmHParams {
     int64_t ldc = 0;
     unsigned short* Ch = nullptr;
     int64_t ldch = 0;
+    unsigned short* ChT = nullptr;               // the same result transposed, bf16 [N, ldcht] with ldcht % 64 == 0, >= M; columns M .. are zero
+    int64_t ldcht = 0;
     const float* bias = nullptr;
     int epi = EPI_NONE;                          // NONE | RELU | GELU (+ out2h = pre-activation) | TANH | ADD_AUX (aux f32) | MUL_GELU_GRAD (auxh bf16)
     const float* aux = nullptr;

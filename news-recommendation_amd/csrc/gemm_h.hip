@@ -19,6 +19,7 @@
 // queue buys.  Past ~0.9 PFLOP/s needs the 256 x 256, 8-wave, multi-phase schedule (next round).
 #include "common.h"
 #include "gemm.h"
+#include <cstdlib>
 
 namespace nr {
 
@@ -163,6 +164,7 @@ __global__ __launch_bounds__(256, 2) void gemm_h_kernel(const GemmHParams p) {
     const int epi = partial ? EPI_NONE : p.epi;
     const bool ub = !partial && p.bias != nullptr;
     unsigned short* Ch = partial ? nullptr : p.Ch;
+    unsigned short* ChT = partial ? nullptr : p.ChT;
     const int mw = m0 + wr * 64, nw = n0 + wc * 64;
     const int cc = (lane & 7) * 8;                          // 8 columns per lane, 8 rows per wave instruction
     const int n = nw + cc;
@@ -174,7 +176,7 @@ __global__ __launch_bounds__(256, 2) void gemm_h_kernel(const GemmHParams p) {
     for (int it = 0; it < 8; ++it) {
         const int rr = it * 8 + (lane >> 3);
         const int m = mw + rr;
-        if (m >= p.M || n >= p.N) continue;
+        if (m >= p.M || n >= p.N) continue;                 // (their LDS rows keep raw accumulators: the transposed pass masks them)
         float v[8];
         {
             const float4 t0 = *reinterpret_cast<const float4*>(tile + rr * EP + cc), t1 = *reinterpret_cast<const float4*>(tile + rr * EP + cc + 4);
@@ -225,6 +227,27 @@ __global__ __launch_bounds__(256, 2) void gemm_h_kernel(const GemmHParams p) {
             if (nfull) *reinterpret_cast<uint4*>(hp) = make_uint4(pack2(v[0], v[1]), pack2(v[2], v[3]), pack2(v[4], v[5]), pack2(v[6], v[7]));
             else for (int e = 0; e < 8; ++e) if (n + e < p.N) hp[e] = f2bf(v[e]);
         }
+        if (ChT) {                                         // park the finished values for the transposed pass below
+            *reinterpret_cast<float4*>(tile + rr * EP + cc) = make_float4(v[0], v[1], v[2], v[3]);
+            *reinterpret_cast<float4*>(tile + rr * EP + cc + 4) = make_float4(v[4], v[5], v[6], v[7]);
+        }
+    }
+    if (ChT) {
+        // transposed copy [n][m]: lane = (column of an 8-column group, 8-row chunk) -> one wave instruction writes 8 output
+        // rows x 128 contiguous bytes; rows m >= M of the tile are written as zeros up to the padded pitch
+        __syncthreads();
+        const int c8 = lane >> 3, mq = lane & 7;
+        const int mbase = mw + mq * 8;
+#pragma unroll 2
+        for (int g8 = 0; g8 < 8; ++g8) {
+            const int col = g8 * 8 + c8;
+            const int nn = nw + col;
+            if (nn >= p.N || mbase >= p.ldcht) continue;
+            float e[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) e[k] = (mbase + k < p.M) ? tile[(mq * 8 + k) * EP + col] : 0.f;
+            *reinterpret_cast<uint4*>(ChT + (int64_t)nn * p.ldcht + mbase) = make_uint4(pack2(e[0], e[1]), pack2(e[2], e[3]), pack2(e[4], e[5]), pack2(e[6], e[7]));
+        }
     }
 }
 
@@ -241,10 +264,14 @@ __global__ __launch_bounds__(256) void splitk_sum_kernel(const float* __restrict
 }
 
 int choose_ksplit_h(int M, int N, int K) {
+    static const int forced = getenv("NR_GEMM_H_KSPLIT") ? atoi(getenv("NR_GEMM_H_KSPLIT")) : 0;     // tools/gemm_h_bench.py sweep
+    if (forced > 0) return std::max(1, std::min(forced, K / HK));
     const int tiles = cdiv(M, HM) * cdiv(N, HN);
     const int kt = K / HK;
-    if (tiles >= 512 || kt < 8) return 1;
-    int ks = std::max(cdiv(512, tiles), kt / 16);         // fill the chip twice over, slices of ~16 k-tiles (1024 rows)
+    if (tiles >= 256 || kt < 8) return 1;
+    // one full round of the chip (256 CUs x 2 resident workgroups) and no more: swept on MI355X at the BERT-base dW
+    // shapes (K = 14 080): 144 tiles x 3 = 432 workgroups 712 TFLOP/s (x2 545, x4 577, x13 504); 108 tiles x 4 667; 36 x 13 417-730
+    int ks = std::max(1, 512 / tiles);
     ks = std::min(ks, std::max(1, kt / 4));
     return std::max(ks, 1);
 }
@@ -257,6 +284,7 @@ int gemm_h(GemmHParams p, float* workspace, size_t ws_bytes, hipStream_t s) {
     NR_CHECK_ARG(p.M >= 0 && p.N >= 0 && p.K >= 0, "gemm_h: negative dims");
     if (p.M == 0 || p.N == 0) return NR_OK;
     NR_CHECK_ARG(p.A && p.B && (p.C || p.Ch), "gemm_h: null operand");
+    NR_CHECK_ARG(!p.ChT || (p.ldcht % 64 == 0 && p.ldcht >= p.M && (reinterpret_cast<uintptr_t>(p.ChT) & 15) == 0), "gemm_h: transposed output needs a 64-multiple pitch >= M");
     NR_UNSUPPORTED(!gemm_h_supported(p.M, p.N, p.K), "gemm_h: K=%d must be a positive multiple of %d", p.K, HK);
     auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
     // 16-byte epilogue accesses need aligned bases and row pitches; anything else takes the element-wise path
@@ -268,7 +296,7 @@ int gemm_h(GemmHParams p, float* workspace, size_t ws_bytes, hipStream_t s) {
     float* final_c = p.C;
     const int64_t final_ldc = p.ldc;
     if (p.ksplit > 1) {
-        NR_CHECK_ARG(p.C && !p.Ch && p.epi == EPI_NONE && !p.bias, "gemm_h: split-K writes plain f32 results only");
+        NR_CHECK_ARG(p.C && !p.Ch && !p.ChT && p.epi == EPI_NONE && !p.bias, "gemm_h: split-K writes plain f32 results only");
         const size_t need = gemm_h_workspace_bytes(p.M, p.N, p.ksplit);
         if (!workspace || ws_bytes < need) { set_error("gemm_h: split-K workspace too small (%zu < %zu)", ws_bytes, need); return NR_ERR_WORKSPACE; }
         p.C = workspace;

@@ -24,10 +24,12 @@ int gather_rows(const float* table, int64_t V, int E, const int64_t* ids, int64_
 int scatter_add_rows(const float* grad_rows, const int64_t* ids, int64_t n, int E, int64_t V, int64_t padding_idx,
                      float* grad_table, hipStream_t s);
 int ln_fwd(const float* h, const float* x, const float* gamma, const float* beta, float* y, float* s_out, float* mean,
-           float* rstd, int64_t R, int D, float eps, DropoutCfg dc, hipStream_t s, int64_t x_period = 0);
+           float* rstd, int64_t R, int D, float eps, DropoutCfg dc, hipStream_t s, int64_t x_period = 0,
+           unsigned short* y_h = nullptr);      // y_h: a bf16 copy of y written alongside (the bf16 build's GEMM operand)
 int ln_bwd_blocks(int64_t R);
 int ln_bwd(const float* dy, const float* sin, const float* mean, const float* rstd, const float* gamma, float* ds,
-           float* dh, float* dgamma_part, float* dbeta_part, int64_t R, int D, DropoutCfg dc, hipStream_t s);
+           float* dh, float* dgamma_part, float* dbeta_part, int64_t R, int D, DropoutCfg dc, hipStream_t s,
+           unsigned short* dh_h = nullptr);     // dh_h: a bf16 copy of the dropped-branch gradient (dh, or ds when p == 0)
 int colsum_chunks(int64_t R);
 int pack_plan(const int64_t* mask, const int64_t* title_keep, int64_t N, int T, int* offs, int* info, hipStream_t s);
 int pack_ids(const int64_t* ids, const int* offs, int64_t N, int T, int64_t* ids_packed, int* row_map, hipStream_t s);
@@ -42,7 +44,8 @@ int add_f32(const float* a, const float* b, float* o, int64_t n, hipStream_t s);
 int relu_bwd_f32(const float* dy, const float* y, float* o, int64_t n, hipStream_t s);
 int gelu_bwd_f32(const float* dy, const float* z, float* o, int64_t n, hipStream_t s);
 int mean_f32(const float* v, int n, float* out, hipStream_t s);
-int dropout_f32(const float* x, float* o, int64_t n, DropoutCfg dc, hipStream_t s);
+int dropout_f32(const float* x, float* o, int64_t n, DropoutCfg dc, hipStream_t s, int D = 0);
+int unpack_rows(const float* src, const int* row_map, int64_t R, int D, int64_t Rfull, float* dst, hipStream_t s);
 int add_bias_rows_f32(const float* x, const float* b, float* o, int64_t R, int D, hipStream_t s);
 int adam_f32(float* p, const float* g, float* m, float* v, int64_t n, double lr, double b1, double b2, double eps, int64_t step,
              hipStream_t s);

@@ -98,13 +98,19 @@ int scatter_add_rows(const float* grad_rows, const int64_t* ids, int64_t n, int 
 // y = LN(drop(h) + x) * gamma + beta ; optionally stores s = drop(h) + x (may alias h),
 // mean and rstd.  VEC=4 needs D % 4 == 0.  D <= 64*VEC*MAXIT.
 constexpr int LN_MAXIT = 8;
+typedef __bf16 rbf16x2 __attribute__((ext_vector_type(2)));
+typedef float rf32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t pack2_bf16(float lo, float hi) {
+    const rf32x2 v = {lo, hi};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, rbf16x2));        // RNE, v_cvt_pk_bf16_f32
+}
 
 template <int VEC, int IT>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ h, const float* __restrict__ x,
                                                      const float* __restrict__ gamma, const float* __restrict__ beta,
                                                      float* __restrict__ y, float* s_out, float* __restrict__ mean_out,
                                                      float* __restrict__ rstd_out, int64_t R, int D, float eps,
-                                                     DropoutCfg dc, int64_t x_period) {
+                                                     DropoutCfg dc, int64_t x_period, unsigned short* __restrict__ y_h) {
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6);
     if (row >= R) return;
@@ -173,10 +179,12 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ h
             for (int e = 0; e < VEC; ++e) o[e] = (v[it][e] - mean) * rstd * gamma[c + e] + beta[c + e];
             if (VEC == 4) {
                 *reinterpret_cast<float4*>(y + row * D + c) = make_float4(o[0], o[1 % VEC], o[2 % VEC], o[3 % VEC]);
+                if (y_h) *reinterpret_cast<uint2*>(y_h + row * D + c) = make_uint2(pack2_bf16(o[0], o[1 % VEC]), pack2_bf16(o[2 % VEC], o[3 % VEC]));
                 if (s_out) *reinterpret_cast<float4*>(s_out + row * D + c) =
                     make_float4(v[it][0], v[it][1 % VEC], v[it][2 % VEC], v[it][3 % VEC]);
             } else {
                 y[row * D + c] = o[0];
+                if (y_h) y_h[row * D + c] = (unsigned short)(pack2_bf16(o[0], 0.f) & 0xffffu);
                 if (s_out) s_out[row * D + c] = v[it][0];
             }
         }
@@ -184,13 +192,13 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ h
 }
 
 int ln_fwd(const float* h, const float* x, const float* gamma, const float* beta, float* y, float* s_out, float* mean,
-           float* rstd, int64_t R, int D, float eps, DropoutCfg dc, hipStream_t s, int64_t x_period) {
+           float* rstd, int64_t R, int D, float eps, DropoutCfg dc, hipStream_t s, int64_t x_period, unsigned short* y_h) {
     if (R == 0) return NR_OK;
     NR_UNSUPPORTED(D > 64 * 4 * LN_MAXIT, "layernorm: D=%d > %d", D, 64 * 4 * LN_MAXIT);
     ProfScope prof(FAM_LN, s, (double)R * D * 4 * (x ? 4 : 3));
     const int grid = cdiv(R, WAVES_PER_BLOCK);
     const bool vec = (D % 4 == 0) && aligned16(h, x, y, s_out);
-#define NR_LN_FWD(V, I) hipLaunchKernelGGL((ln_fwd_kernel<V, I>), dim3(grid), dim3(256), 0, s, h, x, gamma, beta, y, s_out, mean, rstd, R, D, eps, dc, x_period)
+#define NR_LN_FWD(V, I) hipLaunchKernelGGL((ln_fwd_kernel<V, I>), dim3(grid), dim3(256), 0, s, h, x, gamma, beta, y, s_out, mean, rstd, R, D, eps, dc, x_period, y_h)
     if (vec) {
         if (D <= 512) NR_LN_FWD(4, 2); else if (D <= 1024) NR_LN_FWD(4, 4); else NR_LN_FWD(4, 8);
     } else {
@@ -210,7 +218,8 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
                                                      const float* __restrict__ mean_in, const float* __restrict__ rstd_in,
                                                      const float* __restrict__ gamma, float* __restrict__ ds,
                                                      float* __restrict__ dh, float* __restrict__ dgamma_part,
-                                                     float* __restrict__ dbeta_part, int64_t R, int D, DropoutCfg dc) {
+                                                     float* __restrict__ dbeta_part, int64_t R, int D, DropoutCfg dc,
+                                                     unsigned short* __restrict__ dh_h) {
     __shared__ float red[WAVES_PER_BLOCK][2][64 * 4 * LN_MAXIT / 4];   // sized for D<=512 via chunks (see below)
     const int lane = threadIdx.x & 63;
     const int wid = threadIdx.x >> 6;
@@ -278,9 +287,11 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
                 if (VEC == 4) {
                     *reinterpret_cast<float4*>(ds + row * D + c) = make_float4(o[0], o[1 % VEC], o[2 % VEC], o[3 % VEC]);
                     if (dh) *reinterpret_cast<float4*>(dh + row * D + c) = make_float4(od[0], od[1 % VEC], od[2 % VEC], od[3 % VEC]);
+                    if (dh_h) *reinterpret_cast<uint2*>(dh_h + row * D + c) = make_uint2(pack2_bf16(od[0], od[1 % VEC]), pack2_bf16(od[2 % VEC], od[3 % VEC]));
                 } else {
                     ds[row * D + c] = o[0];
                     if (dh) dh[row * D + c] = od[0];
+                    if (dh_h) dh_h[row * D + c] = (unsigned short)(pack2_bf16(od[0], 0.f) & 0xffffu);
                 }
             }
         }
@@ -311,13 +322,13 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
 int ln_bwd_blocks(int64_t R) { return (int)std::min<int64_t>(cdiv(R, WAVES_PER_BLOCK), 1024); }
 
 int ln_bwd(const float* dy, const float* sin, const float* mean, const float* rstd, const float* gamma, float* ds,
-           float* dh, float* dgamma_part, float* dbeta_part, int64_t R, int D, DropoutCfg dc, hipStream_t s) {
+           float* dh, float* dgamma_part, float* dbeta_part, int64_t R, int D, DropoutCfg dc, hipStream_t s, unsigned short* dh_h) {
     if (R == 0) return NR_OK;
     NR_UNSUPPORTED(D > 64 * 4 * LN_MAXIT, "layernorm bwd: D=%d > %d", D, 64 * 4 * LN_MAXIT);
     ProfScope prof(FAM_LN, s, (double)R * D * 4 * (dh ? 4 : 3));
     const int grid = ln_bwd_blocks(R);
     const bool vec = (D % 4 == 0) && aligned16(dy, sin, ds, dh);
-#define NR_LN_BWD(V, I) hipLaunchKernelGGL((ln_bwd_kernel<V, I>), dim3(grid), dim3(256), 0, s, dy, sin, mean, rstd, gamma, ds, dh, dgamma_part, dbeta_part, R, D, dc)
+#define NR_LN_BWD(V, I) hipLaunchKernelGGL((ln_bwd_kernel<V, I>), dim3(grid), dim3(256), 0, s, dy, sin, mean, rstd, gamma, ds, dh, dgamma_part, dbeta_part, R, D, dc, dh_h)
     if (vec) {
         if (D <= 512) NR_LN_BWD(4, 2); else if (D <= 1024) NR_LN_BWD(4, 4); else NR_LN_BWD(4, 8);
     } else {
@@ -544,12 +555,6 @@ int colsum2(const float* a, const float* b, int64_t R, int N, float* out_a, floa
 }
 
 // ------------------------------------------------------------------ bf16 shadow copies (the bf16 build, gemm_h.hip)
-typedef __bf16 rbf16x2 __attribute__((ext_vector_type(2)));
-typedef float rf32x2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ uint32_t pack2_bf16(float lo, float hi) {
-    const rf32x2 v = {lo, hi};
-    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, rbf16x2));        // RNE, v_cvt_pk_bf16_f32
-}
 // y[i] = bf16(x[i]); n % 8 == 0 and 16-byte aligned pointers take the vector path
 __global__ __launch_bounds__(256) void cast_bf16_kernel(const float* __restrict__ x, unsigned short* __restrict__ y, int64_t n, int vec) {
     if (vec) {
@@ -696,12 +701,18 @@ int gelu_bwd_f32(const float* dy, const float* z, float* o, int64_t n, hipStream
 
 // out[i] = keep(i) ? x[i] / (1-p) : 0   (a dropout site that is not followed by a LayerNorm: BERT's embedding
 // dropout; the same call with the same (seed, site) is its backward)
-__global__ __launch_bounds__(256) void dropout_kernel(const float* __restrict__ x, float* __restrict__ o, int64_t n, DropoutCfg dc) {
+// With dc.row_map (packed rows of width D, D % 4 == 0) the keep-bits are those of the ORIGINAL element row_map[r]*D + c.
+__global__ __launch_bounds__(256) void dropout_kernel(const float* __restrict__ x, float* __restrict__ o, int64_t n, DropoutCfg dc, int D) {
     const uint32_t thr = drop_threshold(dc.p);
     const float scale = 1.0f / (1.0f - dc.p);
     const int64_t nq = (n + 3) >> 2;
     for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < nq; q += (int64_t)gridDim.x * blockDim.x) {
-        const Philox4 rn = philox4x32_10(dc.seed, (uint64_t)q, dc.site);
+        uint64_t ctr = (uint64_t)q;
+        if (dc.row_map) {
+            const int64_t r = (q * 4) / D, c = q * 4 - r * D;
+            ctr = (uint64_t)((int64_t)dc.row_map[r] * D + c) >> 2;
+        }
+        const Philox4 rn = philox4x32_10(dc.seed, ctr, dc.site);
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             const int64_t i = q * 4 + e;
@@ -709,11 +720,32 @@ __global__ __launch_bounds__(256) void dropout_kernel(const float* __restrict__ 
         }
     }
 }
-int dropout_f32(const float* x, float* o, int64_t n, DropoutCfg dc, hipStream_t s) {
+int dropout_f32(const float* x, float* o, int64_t n, DropoutCfg dc, hipStream_t s, int D) {
     if (n == 0) return NR_OK;
+    NR_CHECK_ARG(!dc.row_map || (D > 0 && D % 4 == 0), "dropout (packed rows): the row width must be a multiple of 4");
     ProfScope prof(FAM_MISC, s, (double)n * 8);
-    hipLaunchKernelGGL(dropout_kernel, dim3((int)std::min<int64_t>(cdiv(cdiv(n, 4), 256), 8192)), dim3(256), 0, s, x, o, n, dc);
+    hipLaunchKernelGGL(dropout_kernel, dim3((int)std::min<int64_t>(cdiv(cdiv(n, 4), 256), 8192)), dim3(256), 0, s, x, o, n, dc, D);
     return check_launch("dropout");
+}
+
+// dst[row_map[r], :] = src[r, :] over a zeroed dst [Rfull, D]: packed rows back to the padded layout (the position-row
+// gradient of the BERT embedding stage sums over titles per position)
+__global__ __launch_bounds__(256) void unpack_rows_kernel(const float* __restrict__ src, const int* __restrict__ row_map, int64_t R, int D,
+                                                          float* __restrict__ dst) {
+    const int lane = threadIdx.x & 63;
+    const int64_t r = (int64_t)blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6);
+    if (r >= R) return;
+    const float* sp = src + r * D;
+    float* dp = dst + (int64_t)row_map[r] * D;
+    for (int c = lane * 4; c < D; c += 256) *reinterpret_cast<float4*>(dp + c) = *reinterpret_cast<const float4*>(sp + c);
+}
+int unpack_rows(const float* src, const int* row_map, int64_t R, int D, int64_t Rfull, float* dst, hipStream_t s) {
+    NR_CHECK_ARG(D % 4 == 0 && aligned16(src, dst), "unpack_rows: D %% 4 == 0 and 16-byte aligned tensors");
+    if (hipMemsetAsync(dst, 0, (size_t)Rfull * D * sizeof(float), s) != hipSuccess) { set_error("unpack_rows: memset failed"); return NR_ERR_LAUNCH; }
+    if (R == 0) return NR_OK;
+    ProfScope prof(FAM_MISC, s, (double)(R + Rfull) * D * 4);
+    hipLaunchKernelGGL(unpack_rows_kernel, dim3(cdiv(R, WAVES_PER_BLOCK)), dim3(256), 0, s, src, row_map, R, D, dst);
+    return check_launch("unpack_rows");
 }
 
 // out[r, :] = x[r, :] + b[:]

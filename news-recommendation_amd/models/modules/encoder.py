@@ -199,15 +199,16 @@ class HipBertModel(nn.Module):
         model.load_state_dict(clean, strict=True)
         return model
 
-    def forward(self, token_id, attn_mask):
-        """ids/mask [M,T] -> last_hidden_state [M,T,D]"""
+    def forward(self, token_id, attn_mask, plan=None):
+        """ids/mask [M,T] -> last_hidden_state [M,T,D]; with a PackPlan, token_id is the packed id vector [rows] and the
+        result the packed [rows, D] states"""
         e = self.embeddings
         p = self.dropout_p if self.training else 0.0
         seed, site = ops.dropout_stream.next(1) if p > 0 else (0, 0)
         x = ops.bert_embeddings(e.word_embeddings.weight, e.position_embeddings.weight, e.token_type_embeddings.weight,
-                                e.LayerNorm.weight, e.LayerNorm.bias, token_id, e.LayerNorm.eps, p, seed, site)
+                                e.LayerNorm.weight, e.LayerNorm.bias, token_id, e.LayerNorm.eps, p, seed, site, plan=plan)
         for layer in self.encoder.layer:
-            x = layer(x, attention_mask=attn_mask)
+            x = layer(x, attention_mask=attn_mask, plan=plan)
         return x
 
 
@@ -234,6 +235,21 @@ class AllBertNewsEncoder(BaseNewsEncoder):
         tok = self.plm(token_id.reshape(-1, T), attn_mask.reshape(-1, T))
         news = tok[:, 0].reshape(*shape[:-1], -1)
         return tok.view(*shape, -1), news
+
+    def news_vectors(self, token_id, attn_mask, title_keep=None):
+        """the [CLS] vectors alone, over the real token rows only (packed title tokens, include/newsrec_hip.h): HF's masked
+        keys are excluded outright, so a padded position reaches neither another token nor the [CLS] row.  Same numbers as
+        forward()[1]; titles `title_keep` marks 0 are not encoded."""
+        shape = token_id.shape
+        T = shape[-1]
+        cfg = self.plm.cfg
+        ok = T <= 32 and cfg["hidden_size"] // cfg["num_attention_heads"] <= 64 and not getattr(self, "no_packing", False)
+        packed = ops.pack_titles(token_id.reshape(-1, T), attn_mask.reshape(-1, T), title_keep) if ok else None
+        if packed is None:
+            return self.forward(token_id, attn_mask)[1]
+        ids_p, plan = packed
+        tok = self.plm(ids_p, attn_mask.reshape(-1, T), plan=plan)
+        return ops.first_rows(tok, plan).view(*shape[:-1], -1)
 
 
 class RnnUserEncoder(BaseUserEncoder):

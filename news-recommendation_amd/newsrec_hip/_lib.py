@@ -39,7 +39,7 @@ class TfmSaved(C.Structure):
 
 
 class TfmSavedBf16(C.Structure):
-    _fields_ = [(n, c_fp) for n in ("x_h", "qkv_h", "ctx_h", "y1_h", "z_h", "a_h", "s1", "y1", "s2", "stats", "row_max", "row_sum", "w_h")]
+    _fields_ = [(n, c_fp) for n in ("x_h", "qkv_h", "ctx_h", "y1_h", "z_h", "a_h", "s1", "y1", "s2", "stats", "row_max", "row_sum", "w_h", "aT_h")]
 
 
 _SIGS = {
@@ -99,11 +99,17 @@ _SIGS = {
     "nr_transpose_bf16": (c_int, [c_fp, c_int, c_i64, c_i64, c_i64, c_fp, c_i64, c_fp]),
     "nr_gemm_nt_bf16_ws_bytes": (c_sz, [c_i64, c_i64, c_i64, c_int]),
     "nr_gemm_nt_bf16": (c_int, [c_fp, c_fp, c_fp, c_i64, c_i64, c_i64, c_int, c_fp, c_fp, c_fp, c_int, c_fp, c_sz, c_fp]),
-    "nr_tfm_layer_fwd_bf16": (c_int, [c_fp, c_fp, c_i64, c_i64, c_i64, c_i64, C.POINTER(TfmWeights), c_f, c_u64, c_u32, c_int,
+    "nr_tfm_layer_fwd_bf16": (c_int, [c_fp, c_fp, c_fp, c_fp, c_i64, c_i64, c_i64, c_i64, c_i64, C.POINTER(TfmWeights), c_f, c_u64, c_u32, c_int,
                                       C.POINTER(TfmSavedBf16), c_fp, c_fp]),
-    "nr_tfm_layer_bwd_bf16_ws_bytes": (c_sz, [c_i64, c_i64, c_i64]),
-    "nr_tfm_layer_bwd_bf16": (c_int, [c_fp, c_fp, c_i64, c_i64, c_i64, c_i64, C.POINTER(TfmWeights), c_f, c_u64, c_u32, c_int,
+    "nr_tfm_layer_bwd_bf16_ws_bytes": (c_sz, [c_i64, c_i64]),
+    "nr_tfm_layer_bwd_bf16": (c_int, [c_fp, c_fp, c_fp, c_fp, c_i64, c_i64, c_i64, c_i64, c_i64, C.POINTER(TfmWeights), c_f, c_u64, c_u32, c_int,
                                       C.POINTER(TfmSavedBf16), C.POINTER(TfmGrads), c_fp, c_fp, c_sz, c_fp]),
+    "nr_add_layernorm_packed_fwd_f32": (c_int, [c_fp, c_fp, c_i64, c_fp, c_fp, c_fp, c_i64, c_i64, c_f, c_f, c_u64, c_u32,
+                                                c_fp, c_fp, c_fp, c_fp, c_fp]),
+    "nr_add_layernorm_packed_bwd_f32": (c_int, [c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_i64, c_i64, c_f, c_u64, c_u32,
+                                                c_fp, c_fp, c_fp, c_fp, c_fp, c_sz, c_fp]),
+    "nr_dropout_packed_f32": (c_int, [c_fp, c_fp, c_i64, c_i64, c_f, c_u64, c_u32, c_fp, c_fp]),
+    "nr_unpack_rows_f32": (c_int, [c_fp, c_fp, c_i64, c_i64, c_i64, c_fp, c_fp]),
     "nr_gru_fwd_ws_bytes": (c_sz, [c_i64, c_i64]),
     "nr_gru_fwd_f32": (c_int, [c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_i64, c_i64, c_i64, c_i64, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp,
                                c_sz, c_fp]),

@@ -423,29 +423,35 @@ class _TFMLayerBf16(torch.autograd.Function):
     residual stream / LayerNorm / softmax / parameter gradients f32"""
 
     @staticmethod
-    def forward(ctx, x, mask, H, p, seed, site, mask_mode, *params):
-        N, S, D = x.shape
-        R = N * S
+    def forward(ctx, x, mask, H, p, seed, site, mask_mode, plan, *params):
+        N, S = mask.shape
+        D = x.shape[-1]
+        R = N * S if plan is None else plan.rows
         dev = x.device
         h = lambda *shape: torch.empty(*shape, dtype=torch.bfloat16, device=dev)
         f = lambda *shape: torch.empty(*shape, dtype=torch.float32, device=dev)
         bufs = dict(x_h=h(R, D), qkv_h=h(R, 3 * D), ctx_h=h(R, D), y1_h=h(R, D), z_h=h(R, 4 * D), a_h=h(R, 4 * D), s1=f(R, D), y1=f(R, D),
                     s2=f(R, D), stats=f(4, R), row_max=f(N, H, S), row_sum=f(N, H, S), w_h=h(12 * D * D))
+        if any(ctx.needs_input_grad):
+            bufs["aT_h"] = h(4 * D, (R + 63) // 64 * 64)      # GELU output transposed, written by the FFN1 epilogue for dW2
         y = torch.empty_like(x)
         W = TfmWeights(*[_p(t) for t in params])
-        SV = TfmSavedBf16(*[_p(bufs[n]) for n, _ in TfmSavedBf16._fields_])
-        check(lib().nr_tfm_layer_fwd_bf16(_p(x), _p(mask), N, S, D, H, C.byref(W), p, seed, site, mask_mode, C.byref(SV), _p(y), _stream()),
-              "nr_tfm_layer_fwd_bf16")
+        SV = TfmSavedBf16(*[_p(bufs.get(n)) for n, _ in TfmSavedBf16._fields_])
+        offs, row_map = (None, None) if plan is None else (plan.offs, plan.row_map)
+        check(lib().nr_tfm_layer_fwd_bf16(_p(x), _p(mask), _p(offs), _p(row_map), N, S, R, D, H, C.byref(W), p, seed, site, mask_mode,
+                                          C.byref(SV), _p(y), _stream()), "nr_tfm_layer_fwd_bf16")
         if any(ctx.needs_input_grad):
             bufs.pop("y1"), bufs.pop("w_h")                 # forward-only scratch
             ctx.names = list(bufs)
             ctx.save_for_backward(mask, *bufs.values(), *params)
-            ctx.cfg = (N, S, D, H, p, seed, site, mask_mode)
+            ctx.cfg = (N, S, D, H, p, seed, site, mask_mode, plan, tuple(x.shape))
         return y
 
     @staticmethod
     def backward(ctx, g):
-        N, S, D, H, p, seed, site, mask_mode = ctx.cfg
+        N, S, D, H, p, seed, site, mask_mode, plan, xshape = ctx.cfg
+        R = N * S if plan is None else plan.rows
+        offs, row_map = (None, None) if plan is None else (plan.offs, plan.row_map)
         saved = ctx.saved_tensors
         mask, rest = saved[0], saved[1:]
         bufs = dict(zip(ctx.names, rest[:len(ctx.names)]))
@@ -458,12 +464,12 @@ class _TFMLayerBf16(torch.autograd.Function):
         grads = {n: torch.empty_like(t) for n, t in zip(_TFM_ORDER, params) if n not in ("wq", "wk", "wv", "bq", "bk", "bv")}
         grads.update(wq=gqkv_w[0], wk=gqkv_w[1], wv=gqkv_w[2], bq=gqkv_b[0], bk=gqkv_b[1], bv=gqkv_b[2])
         G = TfmGrads(*[_p(grads[n]) for n in _TFM_ORDER])
-        dx = torch.empty(N, S, D, dtype=torch.float32, device=g.device)
+        dx = torch.empty(xshape, dtype=torch.float32, device=g.device)
         L = lib()
-        ws = _ws(L.nr_tfm_layer_bwd_bf16_ws_bytes(N, S, D), g.device)
-        check(L.nr_tfm_layer_bwd_bf16(_p(g), _p(mask), N, S, D, H, C.byref(W), p, seed, site, mask_mode, C.byref(SV), C.byref(G), _p(dx),
-                                      _p(ws), ws.numel() * 4, _stream()), "nr_tfm_layer_bwd_bf16")
-        return (dx, None, None, None, None, None, None) + tuple(grads[n] for n in _TFM_ORDER)
+        ws = _ws(L.nr_tfm_layer_bwd_bf16_ws_bytes(R, D), g.device)
+        check(L.nr_tfm_layer_bwd_bf16(_p(g), _p(mask), _p(offs), _p(row_map), N, S, R, D, H, C.byref(W), p, seed, site, mask_mode, C.byref(SV),
+                                      C.byref(G), _p(dx), _p(ws), ws.numel() * 4, _stream()), "nr_tfm_layer_bwd_bf16")
+        return (dx, None, None, None, None, None, None, None) + tuple(grads[n] for n in _TFM_ORDER)
 
 
 def _contiguous3(a, b, c):
@@ -495,10 +501,11 @@ def tfm_layer(x, mask, head_num, params, p_drop=0.0, seed=0, site=0, hf_mask=Fal
         want = {"w1": (4 * D, D), "b1": (4 * D,), "w2": (D, 4 * D)}.get(n, (D, D) if n.startswith("w") else (D,))
         if tuple(t.shape) != want:
             raise NewsrecError(f"tfm_layer: parameter {n} has shape {tuple(t.shape)}, expected {want}")
-    if (plan is None and get_gemm_compute() == "bf16" and tfm_layer_bf16_supported(x.shape[1], D, int(head_num)) and x.shape[0] * x.shape[1] >= 128
+    rows = x.shape[0] if plan is not None else x.shape[0] * x.shape[1]
+    if (get_gemm_compute() == "bf16" and tfm_layer_bf16_supported(mask.shape[1], D, int(head_num)) and rows >= 128
             and _contiguous3(plist[0], plist[2], plist[4]) and _contiguous3(plist[1], plist[3], plist[5])):
         # the bf16 build proper: activations / attention tensors bf16 in HBM (BERT-sized layers, parity bar 1e-2)
-        return _TFMLayerBf16.apply(x, mask, int(head_num), float(p_drop), int(seed), int(site), 1 if hf_mask else 0, *plist)
+        return _TFMLayerBf16.apply(x, mask, int(head_num), float(p_drop), int(seed), int(site), 1 if hf_mask else 0, plan, *plist)
     return _TFMLayer.apply(x, mask, int(head_num), float(p_drop), int(seed), int(site), 1 if hf_mask else 0, plan, *plist)
 
 
@@ -580,59 +587,103 @@ class _BertEmbed(torch.autograd.Function):
     """HF BertEmbeddings: dropout(LayerNorm(word[ids] + position[0..T-1] + token_type[0])) over ids [M,T]."""
 
     @staticmethod
-    def forward(ctx, word, pos, typ, gamma, beta, ids, eps, p, seed, site):
-        M, T = ids.shape
+    def forward(ctx, word, pos, typ, gamma, beta, ids, eps, p, seed, site, plan):
+        """ids [M,T], or with a PackPlan the packed ids [rows] (result then [rows, D])"""
+        M, T = ids.shape if plan is None else (plan.N, plan.T)
         D = word.shape[1]
-        R = M * T
+        R = M * T if plan is None else plan.rows
         L = lib()
         pt = torch.empty(T, D, dtype=torch.float32, device=word.device)
         check(L.nr_add_bias_rows_f32(_p(pos), _p(typ), T, D, _p(pt), _stream()), "nr_add_bias_rows_f32")   # pos[:T] + type[0]
         e = gather_rows(word, ids).view(R, D)
         y = torch.empty(R, D, dtype=torch.float32, device=word.device)
         stats = torch.empty(2, R, dtype=torch.float32, device=word.device)
-        check(L.nr_add_layernorm_fwd_f32(_p(e), _p(pt), T, _p(gamma), _p(beta), R, D, eps, 0.0, 0, 0, _p(y), _p(e),
-                                         _p(stats[0]), _p(stats[1]), _stream()), "nr_add_layernorm_fwd_f32")
+        if plan is None:
+            check(L.nr_add_layernorm_fwd_f32(_p(e), _p(pt), T, _p(gamma), _p(beta), R, D, eps, 0.0, 0, 0, _p(y), _p(e),
+                                             _p(stats[0]), _p(stats[1]), _stream()), "nr_add_layernorm_fwd_f32")
+        else:       # the position row of a packed row is that of its ORIGINAL position (row_map[r] % T)
+            check(L.nr_add_layernorm_packed_fwd_f32(_p(e), _p(pt), T, _p(plan.row_map), _p(gamma), _p(beta), R, D, eps, 0.0, 0, 0, _p(y), _p(e),
+                                                    _p(stats[0]), _p(stats[1]), _stream()), "nr_add_layernorm_packed_fwd_f32")
         if p > 0:
             yd = torch.empty_like(y)
-            check(L.nr_dropout_f32(_p(y), y.numel(), p, seed, site, _p(yd), _stream()), "nr_dropout_f32")
+            if plan is None:
+                check(L.nr_dropout_f32(_p(y), y.numel(), p, seed, site, _p(yd), _stream()), "nr_dropout_f32")
+            else:
+                check(L.nr_dropout_packed_f32(_p(y), _p(plan.row_map), R, D, p, seed, site, _p(yd), _stream()), "nr_dropout_packed_f32")
             y = yd
         ctx.save_for_backward(e, stats, gamma, ids)
-        ctx.cfg = (M, T, D, word.shape[0], pos.shape[0], typ.shape[0], p, seed, site)
-        return y.view(M, T, D)
+        ctx.cfg = (M, T, D, word.shape[0], pos.shape[0], typ.shape[0], p, seed, site, plan)
+        return y.view(M, T, D) if plan is None else y
 
     @staticmethod
     def backward(ctx, g):
         s, stats, gamma, ids = ctx.saved_tensors
-        M, T, D, V, NP, NT, p, seed, site = ctx.cfg
-        R = M * T
+        M, T, D, V, NP, NT, p, seed, site, plan = ctx.cfg
+        R = M * T if plan is None else plan.rows
         L = lib()
         g = _f32(g, "grad").reshape(R, D)
         if p > 0:
             gd = torch.empty_like(g)
-            check(L.nr_dropout_f32(_p(g), g.numel(), p, seed, site, _p(gd), _stream()), "nr_dropout_f32")
+            if plan is None:
+                check(L.nr_dropout_f32(_p(g), g.numel(), p, seed, site, _p(gd), _stream()), "nr_dropout_f32")
+            else:
+                check(L.nr_dropout_packed_f32(_p(g), _p(plan.row_map), R, D, p, seed, site, _p(gd), _stream()), "nr_dropout_packed_f32")
             g = gd
         ds = torch.empty(R, D, dtype=torch.float32, device=g.device)
         dgamma = torch.empty(D, dtype=torch.float32, device=g.device)
         dbeta = torch.empty(D, dtype=torch.float32, device=g.device)
         ws = _ws(L.nr_layernorm_bwd_ws_bytes(R, D), g.device)
         check(L.nr_add_layernorm_bwd_f32(_p(g), _p(s), _p(stats[0]), _p(stats[1]), _p(gamma), R, D, 0.0, 0, 0, _p(ds), None,
-                                         _p(dgamma), _p(dbeta), _p(ws), ws.numel() * 4, _stream()), "nr_add_layernorm_bwd_f32")
+                                         _p(dgamma), _p(dbeta), _p(ws), ws.numel() * 4, _stream()), "nr_add_layernorm_bwd_f32")   # (no dropout inside: row_map not needed)
         dword = torch.zeros(V, D, dtype=torch.float32, device=g.device)
         check(L.nr_scatter_add_rows_f32(_p(ds), _p(ids), R, D, V, PAD_ID, _p(dword), _stream()), "nr_scatter_add_rows_f32")
         dpos = torch.zeros(NP, D, dtype=torch.float32, device=g.device)
-        dpos[:T] = colsum(ds.view(M, T * D)).view(T, D)            # every title adds position rows 0..T-1
+        if plan is None:
+            ds_full = ds
+        else:                                                        # packed rows back to [M*T, D] (zeros at dropped positions)
+            ds_full = torch.empty(M * T, D, dtype=torch.float32, device=g.device)
+            check(L.nr_unpack_rows_f32(_p(ds), _p(plan.row_map), R, D, M * T, _p(ds_full), _stream()), "nr_unpack_rows_f32")
+        dpos[:T] = colsum(ds_full.view(M, T * D)).view(T, D)        # every title adds position rows 0..T-1
         dtyp = torch.zeros(NT, D, dtype=torch.float32, device=g.device)
         dtyp[0] = colsum(dpos[:T])                                   # ... and token-type row 0 at every token
-        return dword, dpos, dtyp, dgamma, dbeta, None, None, None, None, None
+        return dword, dpos, dtyp, dgamma, dbeta, None, None, None, None, None, None
 
 
-def bert_embeddings(word, pos, typ, gamma, beta, ids, eps=LN_EPS, p_drop=0.0, seed=0, site=0):
+def bert_embeddings(word, pos, typ, gamma, beta, ids, eps=LN_EPS, p_drop=0.0, seed=0, site=0, plan=None):
     ids = _i64(ids, "token_id")
-    if ids.dim() != 2 or ids.shape[1] > pos.shape[0]:
+    if plan is not None:
+        if ids.dim() != 1 or ids.shape[0] != plan.rows or plan.T > pos.shape[0]:
+            raise NewsrecError(f"bert_embeddings: packed ids {tuple(ids.shape)} do not match the plan ({plan.rows} rows, T = {plan.T})")
+    elif ids.dim() != 2 or ids.shape[1] > pos.shape[0]:
         raise NewsrecError(f"bert_embeddings: ids {tuple(ids.shape)} must be [M,T] with T <= {pos.shape[0]} positions")
     return _BertEmbed.apply(_f32(word, "word_embeddings"), _f32(pos, "position_embeddings"), _f32(typ, "token_type_embeddings"),
                             _f32(gamma, "embeddings.LayerNorm.weight"), _f32(beta, "embeddings.LayerNorm.bias"), ids,
-                            float(eps), float(p_drop), int(seed), int(site))
+                            float(eps), float(p_drop), int(seed), int(site), plan)
+
+
+class _FirstRows(torch.autograd.Function):
+    """x [rows, D] packed -> the first row of every sequence [N, D] ([CLS] states).  Sequences without rows (titles the
+    caller never uses) return whatever row their offset points at: finite, and by the caller's guarantee unused."""
+
+    @staticmethod
+    def forward(ctx, x, plan):
+        idx = plan.offs[:-1].long().clamp_(max=max(plan.rows - 1, 0))
+        ctx.save_for_backward(idx)
+        ctx.shape = x.shape
+        return gather_rows(x, idx)
+
+    @staticmethod
+    def backward(ctx, g):
+        (idx,) = ctx.saved_tensors
+        g = _f32(g, "grad")
+        R, D = ctx.shape
+        dx = torch.zeros(R, D, dtype=torch.float32, device=g.device)
+        check(lib().nr_scatter_add_rows_f32(_p(g), _p(idx), idx.numel(), D, R, -1, _p(dx), _stream()), "nr_scatter_add_rows_f32")
+        return dx, None
+
+
+def first_rows(x, plan):
+    return _FirstRows.apply(_f32(x, "hidden_states"), plan)
 
 
 # ----------------------------------------------------------------------------- projection + query pooling

@@ -566,3 +566,35 @@ def test_tfm_submodules_are_callable_and_compose_to_the_layer():
     layer.train()
     a1 = layer.attention(x.detach(), mask)
     assert relerr(a1, att) > 1e-3
+
+
+@pytest.mark.parametrize("gemm", ["fp32", "bf16"])
+def test_bert_news_vectors_packed_equals_padded(gemm):
+    """AllBertNewsEncoder.news_vectors (packed rows: position rows / dropout bits by original position, [CLS] = first row of
+    each title) against forward()[1] (padded), train mode with dropout, both GEMM builds; incl. all-PAD titles."""
+    from newsrec_hip import ops
+    meta = dict(V=2000, E=256, D=256, H=4, T=32, L=10, K=4, B=4, Nn=300, NL=2)
+    model, mgr = build_model(meta, "bert", "attn")
+    g = torch.Generator().manual_seed(93)
+    ids, msk = synth_news_table(g, meta["Nn"], meta["T"], meta["V"])
+    enc = model.newsEncoder.cuda().train()
+    ids_d, msk_d = ids.cuda().view(3, 100, -1), msk.cuda().view(3, 100, -1)
+    ops.set_gemm_compute(gemm)
+    try:
+        outs = []
+        for fn in (lambda: enc(ids_d, msk_d)[1], lambda: enc.news_vectors(ids_d, msk_d)):
+            enc.zero_grad()
+            torch.manual_seed(3)
+            ops.dropout_stream.reset(0)
+            v = fn()
+            v.square().sum().backward()
+            outs.append((v.detach().clone(), {n: p_.grad.clone() for n, p_ in enc.named_parameters()}))
+    finally:
+        ops.set_gemm_compute("fp32")
+    (va, ga), (vb, gb) = outs
+    tol, gtol = (1e-6, GRAD_TOL) if gemm == "fp32" else (1e-2, 1e-2)     # bf16: the row tiling of the GEMMs differs -> different roundings
+    assert va.shape == vb.shape == (3, 100, 256) and relerr(vb, va) < tol
+    gscale = max(float(v.abs().max()) for v in ga.values())
+    for n in ga:
+        err, ref = (gb[n] - ga[n]).norm().item(), ga[n].norm().item()
+        assert err <= gtol * ref + 3e-6 * gscale * ga[n].numel() ** 0.5, (n, err, ref)

@@ -38,6 +38,11 @@ def run(M, N, K, act=0, split=0, reps=20, check=True, out="both"):
     e1.record(); torch.cuda.synchronize()
     t = e0.elapsed_time(e1) / reps * 1e-3
     print(f"M={M:6d} N={N:5d} K={K:6d} act={act} split={split} out={out}: {2.0*M*N*K/t/1e12:7.1f} TFLOP/s  {t*1e6:7.1f} us  max rel err {err}")
+if __name__ == "__main__" and os.environ.get("NR_GEMM_H_KSPLIT"):
+    R = 14080
+    for (M, N, K) in [(768, 3072, R), (3072, 768, R), (768, 768, R), (2304, 768, R), (768, 3072, 4 * R), (768, 768, 4 * R)]:
+        run(M, N, K, split=1, check=False)
+    sys.exit(0)
 if __name__ == "__main__":
     # transposes
     x = torch.randn(1000, 300, device="cuda"); xt = torch.empty(300, 1024, dtype=torch.bfloat16, device="cuda")
