@@ -30,6 +30,7 @@
 #include "common.h"
 #include "gemm.h"
 #include <atomic>
+#include <cstdlib>
 
 namespace nr {
 
@@ -896,7 +897,12 @@ static int launch_tiled(const GemmParams& p, hipStream_t s) {
 // (only for long reductions: with few k-tiles per split its 80 MFMAs per wave and k-tile serialise on too few CUs)
 // and many n-tiles to share the tall A tile through L2: measured on the NRMS shapes it wins for dW[300,1200]
 // (85 vs 79 TF/s) and loses for dW[900,300] / dW[300,300] (74 vs 78, 51 vs 59)
-static bool tall_tile(int M, int N, int K) { return K >= 8192 && N >= 1024 && cdiv(M, 320) * 320 < cdiv(M, 128) * 128; }
+static bool tall_tile(int M, int N, int K) {
+    static const bool off = getenv("NR_GEMM_NO_TALL") != nullptr;       // A/B switch for tools
+    // R = 56 320 rows (the padded NRMS step): 85 vs 79 TF/s for dW[300,1200]; at the ~22 000 rows of the packed step the
+    // 64-row tile wins (step 3.255 -> 3.215 ms): long reductions only
+    return !off && K >= 40000 && N >= 1024 && cdiv(M, 320) * 320 < cdiv(M, 128) * 128;
+}
 // ... and 64-row tiles when they pad M less than 128-row ones (M = 300: 320 vs 384 rows; dW[300,300] 52 -> 66 TF/s,
 // dW[900,300] 78 -> 83, dW[1200,300] 84 -> 90)
 static bool short_tile(int M) { return cdiv(M, 64) * 64 < cdiv(M, 128) * 128; }
@@ -971,6 +977,8 @@ int gemm_f32(GemmParams p, bool a_kc, bool b_kc, float* workspace, size_t ws_byt
         else                     rc = launch_bf16<false, false>(q, s);
     } else {
     // BN=128 only when it wastes no more columns than BN=64
+    // BN=128 only when it pads no more columns than BN=64: at N=1200 (6.7 % vs 1.3 % padding) the wide tile measured
+    // 9 489 vs 9 928 impressions/s on the whole step (r02 A/B), the extra columns cost more than the saved A re-reads
     const bool wide = (cdiv(p.N, 128) * 128 == cdiv(p.N, 64) * 64) && p.N >= 128;
     // few 128-row tiles (the user tower: 1600 history rows) leave most CUs idle: halve the tile
     // ... and so does a short, narrow product (N <= 320, K <= 512: out-proj / pooling projection at 300-d, +5-9 %):

@@ -463,7 +463,7 @@ def test_full_size_step_properties():
     assert torch.equal(l0, l1)
     for n in g0:
         if "embedding" in n:                   # float atomics: order-dependent in the last bits
-            assert relerr(g1[n], g0[n]) < 1e-6, n
+            assert relerr(g1[n], g0[n]) < 5e-6, n
         else:
             assert torch.equal(g0[n], g1[n]), n
     # linearity of the dense product at R = 56 320
