@@ -373,6 +373,7 @@ def main():
         else:
             opt.zero_grad(set_to_none=True)
         loss = net(batches[i % len(batches)])
+        model.plan_ahead(batches[(i + 1) % len(batches)])     # as Manager._train does: the next batch's pack plan, one step early
         loss.backward()
         if world > 1:
             if time_sync:

@@ -160,11 +160,11 @@ class TwoTowerBaseModel(BaseModel):
         idx = x[key + "_idx"].to(self.device)
         return ops.gather_rows_i64(self._news_token_ids, idx), ops.gather_rows_i64(self._news_attn_masks, idx)
 
-    def _news_vectors(self, token_id, attn_mask, title_keep=None):
+    def _news_vectors(self, token_id, attn_mask, title_keep=None, pending=None):
         """news vectors only: encoders that offer `news_vectors` skip the padded token rows, and the titles
         `title_keep` marks 0 (same results wherever they are used)"""
         fn = getattr(self.newsEncoder, "news_vectors", None)
-        return fn(token_id, attn_mask, title_keep) if fn is not None else self.newsEncoder(token_id, attn_mask)[1]
+        return fn(token_id, attn_mask, title_keep, pending) if fn is not None else self.newsEncoder(token_id, attn_mask)[1]
 
     def _corpus_vectors(self, x):
         """news vectors of one chunk of the corpus (encode_news); token embeddings are not needed there"""
@@ -180,11 +180,8 @@ class TwoTowerBaseModel(BaseModel):
             his_mask = x["his_mask"].to(self.device)
         return self.userEncoder(his_news_embedding, his_mask=his_mask)
 
-    def forward(self, x):
-        """mean softmax-CE of the clicked candidate (label 0) among 1+K candidates (reference
-        BaseModel.py:198-205).  Titles are encoded independently of each other, so the candidate and
-        history titles of the batch go through the news encoder as ONE [B, C+L, T] call (the reference
-        makes two calls; per-title results are identical) and are split afterwards."""
+    def _train_inputs(self, x):
+        """the tensors forward() works on: (C, ids [B,C+L,T], masks, his_mask, keep, pending pack plan)"""
         if "cdd_token_id" in x:
             cdd_ids = x["cdd_token_id"].to(self.device)
             C = cdd_ids.shape[1]
@@ -199,7 +196,24 @@ class TwoTowerBaseModel(BaseModel):
             # history slots the user encoder masks out cannot reach the loss: as masked keys / skipped GRU steps their
             # weight is exactly 0 and so is every gradient into them -> those titles are not encoded at all
             keep = torch.cat([torch.ones_like(his_mask[:, :1]).expand(-1, C), self.userEncoder.history_keep(his_mask)], dim=1)
-        news = self._news_vectors(ids, masks, keep)
+        begin = getattr(self.newsEncoder, "plan_begin", None)
+        pending = begin(ids, masks, keep) if begin is not None else None
+        return C, ids, masks, his_mask, keep, pending
+
+    def plan_ahead(self, x):
+        """optional look-ahead for a training loop that already holds its NEXT batch: assemble that batch's title tensors
+        and queue its pack plan now.  forward(x) on the same dict then finds the row count on the host and the step runs
+        without a device->host wait (the only one the packed path has).  Same results with or without this call."""
+        self._ahead = (x, self._train_inputs(x))
+
+    def forward(self, x):
+        """mean softmax-CE of the clicked candidate (label 0) among 1+K candidates (reference
+        BaseModel.py:198-205).  Titles are encoded independently of each other, so the candidate and
+        history titles of the batch go through the news encoder as ONE [B, C+L, T] call (the reference
+        makes two calls; per-title results are identical) and are split afterwards."""
+        ahead, self._ahead = getattr(self, "_ahead", None), None
+        C, ids, masks, his_mask, keep, pending = ahead[1] if ahead is not None and ahead[0] is x else self._train_inputs(x)
+        news = self._news_vectors(ids, masks, keep, pending)
         cdd_news_embedding = news[:, :C]
         user_embedding = self.userEncoder(news[:, C:], his_mask=his_mask)
         labels = x["label"].to(self.device)

@@ -107,18 +107,23 @@ class TfmNewsEncoder(BaseNewsEncoder):
         news, _ = ops.project_and_pool(tok, self.newsProject.weight, self.newsProject.bias, self.news_query, mask)
         return tok.view(*shape, -1), news.view(*shape[:-1], -1)
 
-    def news_vectors(self, token_id, attn_mask, title_keep=None):
+    def plan_begin(self, token_id, attn_mask, title_keep=None):
+        """start the pack plan news_vectors() will need for these titles (ops.pack_titles_begin); None = no packing"""
+        T = token_id.shape[-1]
+        return ops.pack_titles_begin(attn_mask.reshape(-1, T), title_keep) if self.packable(T) else None
+
+    def news_vectors(self, token_id, attn_mask, title_keep=None, pending=None):
         """the news vectors alone, for callers that drop token_embedding (TwoTowerBaseModel.forward / encode_news):
         same numbers as forward()[1], computed over the real token rows only (packed title tokens, include/newsrec_hip.h)
         whenever the masks are prefix-shaped and T <= 32; otherwise through forward().  title_keep [...] 0/1 marks
         titles whose vector the caller never uses (masked history slots): they are not encoded and come back as zeros."""
         shape = token_id.shape
         T = shape[-1]
-        packed = ops.pack_titles(token_id.reshape(-1, T), attn_mask.reshape(-1, T), title_keep) if self.packable(T) else None
+        mask = attn_mask.reshape(-1, T)
+        packed = ops.pack_titles(token_id.reshape(-1, T), mask, title_keep, pending) if self.packable(T) else None
         if packed is None:
             return self.forward(token_id, attn_mask)[1]
         ids_p, plan = packed
-        mask = attn_mask.reshape(-1, T)
         emb = ops.embedding(self.embedding.weight, ids_p, self.embedding.padding_idx)        # [rows, E]
         tok = self.transformer(emb, attention_mask=mask, plan=plan)
         news, _ = ops.project_and_pool(tok, self.newsProject.weight, self.newsProject.bias, self.news_query, mask, plan=plan)
@@ -236,19 +241,26 @@ class AllBertNewsEncoder(BaseNewsEncoder):
         news = tok[:, 0].reshape(*shape[:-1], -1)
         return tok.view(*shape, -1), news
 
-    def news_vectors(self, token_id, attn_mask, title_keep=None):
+    def packable(self, T):
+        cfg = self.plm.cfg
+        return T <= 32 and cfg["hidden_size"] // cfg["num_attention_heads"] <= 64 and not getattr(self, "no_packing", False)
+
+    def plan_begin(self, token_id, attn_mask, title_keep=None):
+        T = token_id.shape[-1]
+        return ops.pack_titles_begin(attn_mask.reshape(-1, T), title_keep) if self.packable(T) else None
+
+    def news_vectors(self, token_id, attn_mask, title_keep=None, pending=None):
         """the [CLS] vectors alone, over the real token rows only (packed title tokens, include/newsrec_hip.h): HF's masked
         keys are excluded outright, so a padded position reaches neither another token nor the [CLS] row.  Same numbers as
         forward()[1]; titles `title_keep` marks 0 are not encoded."""
         shape = token_id.shape
         T = shape[-1]
-        cfg = self.plm.cfg
-        ok = T <= 32 and cfg["hidden_size"] // cfg["num_attention_heads"] <= 64 and not getattr(self, "no_packing", False)
-        packed = ops.pack_titles(token_id.reshape(-1, T), attn_mask.reshape(-1, T), title_keep) if ok else None
+        mask = attn_mask.reshape(-1, T)
+        packed = ops.pack_titles(token_id.reshape(-1, T), mask, title_keep, pending) if self.packable(T) else None
         if packed is None:
             return self.forward(token_id, attn_mask)[1]
         ids_p, plan = packed
-        tok = self.plm(ids_p, attn_mask.reshape(-1, T), plan=plan)
+        tok = self.plm(ids_p, mask, plan=plan)
         return ops.first_rows(tok, plan).view(*shape[:-1], -1)
 
 

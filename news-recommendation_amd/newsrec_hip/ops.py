@@ -126,12 +126,20 @@ class PackPlan:
         self.offs, self.row_map, self.rows, self.N, self.T = offs, row_map, rows, N, T
 
 
-def pack_titles(ids, mask, title_keep=None):
-    """ids / mask [N,T] int64 on the device -> (ids_packed [rows] int64, PackPlan), or None when a mask row is not
-    prefix-shaped (the packing is exact only for those; the caller then takes the padded path).  title_keep [N] 0/1:
-    titles with 0 get no rows at all (the caller guarantees nothing downstream uses their vectors).  One 8-byte
-    device->host read (the row count sizes every later allocation)."""
-    ids, mask = _i64(ids, "token_id"), _i64(mask, "attn_mask")
+class PendingPlan:
+    """a pack plan whose row count is still on its way to the host (pack_titles_begin): the plan kernels and an
+    8-byte copy into pinned memory are queued, `event` marks their end."""
+    __slots__ = ("offs", "info", "host", "event", "N", "T", "mask_ptr")
+
+    def __init__(self, offs, info, host, event, N, T, mask_ptr):
+        self.offs, self.info, self.host, self.event, self.N, self.T, self.mask_ptr = offs, info, host, event, N, T, mask_ptr
+
+
+def pack_titles_begin(mask, title_keep=None):
+    """queue the plan of pack_titles for `mask` / `title_keep` without waiting for it.  A caller that knows its next
+    batch (a training loop with one batch of look-ahead) starts the plan a step early, so that the row count is already
+    on the host when that batch's forward needs it and the step has no device->host wait in it."""
+    mask = _i64(mask, "attn_mask")
     N, T = mask.shape
     if title_keep is not None:
         title_keep = _i64(title_keep, "title_keep").reshape(-1)
@@ -139,14 +147,34 @@ def pack_titles(ids, mask, title_keep=None):
             raise NewsrecError(f"pack_titles: title_keep has {title_keep.numel()} entries for {N} titles")
     offs = torch.empty(N + 1, dtype=torch.int32, device=mask.device)
     info = torch.empty(2, dtype=torch.int32, device=mask.device)
-    L = lib()
-    check(L.nr_pack_plan(_p(mask), _p(title_keep), N, T, _p(offs), _p(info), _stream()), "nr_pack_plan")
-    rows, ok = info.tolist()
+    check(lib().nr_pack_plan(_p(mask), _p(title_keep), N, T, _p(offs), _p(info), _stream()), "nr_pack_plan")
+    host = torch.empty(2, dtype=torch.int32, pin_memory=True)
+    host.copy_(info, non_blocking=True)
+    event = torch.cuda.Event()
+    event.record()
+    return PendingPlan(offs, info, host, event, N, T, mask.data_ptr())
+
+
+def pack_titles(ids, mask, title_keep=None, pending=None):
+    """ids / mask [N,T] int64 on the device -> (ids_packed [rows] int64, PackPlan), or None when a mask row is not
+    prefix-shaped (the packing is exact only for those; the caller then takes the padded path).  title_keep [N] 0/1:
+    titles with 0 get no rows at all (the caller guarantees nothing downstream uses their vectors).  One 8-byte
+    device->host read (the row count sizes every later allocation); `pending` = the PendingPlan of an earlier
+    pack_titles_begin on the same mask / title_keep, whose read has usually finished long ago."""
+    ids, mask = _i64(ids, "token_id"), _i64(mask, "attn_mask")
+    N, T = mask.shape
+    if pending is None:
+        pending = pack_titles_begin(mask, title_keep)
+    elif (pending.N, pending.T, pending.mask_ptr) != (N, T, mask.data_ptr()):
+        raise NewsrecError("pack_titles: the pending plan was started for another mask")
+    pending.event.synchronize()
+    rows, ok = pending.host.tolist()
     if not ok:
         return None
+    offs = pending.offs
     ids_packed = torch.empty(rows, dtype=torch.int64, device=mask.device)
     row_map = torch.empty(rows, dtype=torch.int32, device=mask.device)
-    check(L.nr_pack_ids(_p(ids), _p(offs), N, T, _p(ids_packed), _p(row_map), _stream()), "nr_pack_ids")
+    check(lib().nr_pack_ids(_p(ids), _p(offs), N, T, _p(ids_packed), _p(row_map), _stream()), "nr_pack_ids")
     return ids_packed, PackPlan(offs, row_map, int(rows), N, T)
 
 

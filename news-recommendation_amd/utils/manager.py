@@ -93,6 +93,19 @@ NEWS_NUMS = {"MINDdemo_train": 51282, "MINDdemo_dev": 42416, "MINDsmall_train": 
              "MINDlarge_train": 101527, "MINDlarge_dev": 72023, "MINDlarge_test": 120961}
 
 
+def _with_next(it):
+    """(item, next item or None) pairs of an iterable: one element of look-ahead"""
+    it = iter(it)
+    try:
+        cur = next(it)
+    except StopIteration:
+        return
+    for nxt in it:
+        yield cur, nxt
+        cur = nxt
+    yield cur, None
+
+
 class Manager():
     def __init__(self, config=None, command=None):
         parser = argparse.ArgumentParser()
@@ -264,12 +277,14 @@ class Manager():
                 loader.sampler.set_epoch(epoch)
             epoch_loss = None
             bar = tqdm(loader, ncols=120, disable=self.rank != 0)
-            for step, x in enumerate(bar, 1):
+            for step, (x, x_next) in enumerate(_with_next(bar), 1):
                 if hasattr(model, "sync"):                 # FlatGradSync: gradients live in one flat buffer
                     model.zero_grad()
                 else:
                     optimizer.zero_grad(set_to_none=True)
                 loss = model(x)
+                if x_next is not None and hasattr(core, "plan_ahead"):
+                    core.plan_ahead(x_next)                # the next batch's pack plan rides along with this step
                 loss.backward()
                 if hasattr(model, "sync"):
                     model.sync()

@@ -308,6 +308,39 @@ def test_forward_skips_dead_history_titles_exactly(ue):
         assert (g1[n] - g0[n]).abs().max().item() <= GRAD_TOL * g0[n].abs().max().item() + 3e-6 * gscale, n
 
 
+def test_plan_ahead_changes_nothing():
+    """TwoTowerBaseModel.plan_ahead(x) (the pack plan of the next batch, queued a step early as Manager._train does)
+    followed by forward(x): loss and gradients are bit-equal to forward(x) alone; a plan started for another batch is
+    never used (the dict identity is checked)."""
+    from newsrec_hip import ops
+    meta = dict(V=30522, E=300, D=300, H=12, T=32, L=50, K=4, B=8, Nn=2000)
+    model, mgr = build_model(meta, "tfm", "tfm")
+    g = torch.Generator().manual_seed(55)
+    ids, msk = synth_news_table(g, meta["Nn"], meta["T"], meta["V"])
+    X = {k: v.cuda() for k, v in synth_batch(g, meta["B"], meta["K"] + 1, meta["L"], meta["Nn"], ids, msk).items()}
+    Y = {k: v.cuda() for k, v in synth_batch(g, meta["B"], meta["K"] + 1, meta["L"], meta["Nn"], ids, msk).items()}
+    model = model.cuda().train()
+    runs = []
+    for mode in ("plain", "ahead", "ahead_of_other"):
+        model.zero_grad(set_to_none=True)
+        ops.dropout_stream.reset(0)
+        if mode == "ahead":
+            model.plan_ahead(X)
+        elif mode == "ahead_of_other":
+            model.plan_ahead(Y)
+        loss = model(X)
+        assert model._ahead is None
+        loss.backward()
+        runs.append((loss.detach().clone(), {n: p_.grad.detach().clone() for n, p_ in model.named_parameters()}))
+    for l, gr in runs[1:]:
+        assert torch.equal(l, runs[0][0])
+        for n in gr:
+            if "embedding" in n:        # scatter-add by atomics: order-dependent in the last bits
+                assert (gr[n] - runs[0][1][n]).abs().max().item() <= 5e-6 * runs[0][1][n].abs().max().item(), n
+            else:
+                assert torch.equal(gr[n], runs[0][1][n]), n
+
+
 def test_nrms_train_step_vs_oracle():
     """BASELINE config 2 shape (T=32, L=50, K=4, 300-d, 12 heads) at B=8: loss, every gradient and one Adam
     step against the oracle (eval-mode dropout so the comparison is deterministic)."""

@@ -300,3 +300,10 @@ def test_min_rank_restatement_equals_scipy_rankdata():
     sizes = [int(v) for v in z["rank_sizes"]]
     got = np.concatenate([min_ranks(g) for g in np.split(scores[order], np.cumsum(sizes)[:-1])])
     assert np.array_equal(got, z["ranks"])
+
+
+def test_with_next_yields_one_item_of_lookahead():
+    from utils.manager import _with_next
+    assert list(_with_next([])) == []
+    assert list(_with_next([1])) == [(1, None)]
+    assert list(_with_next(iter([1, 2, 3]))) == [(1, 2), (2, 3), (3, None)]
