@@ -306,7 +306,7 @@ def main():
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="nrms",
                     help="nrms = the headline workload (BASELINE configs[1]); the others are extra measurements "
                          "(no roofline/cpu_baseline/eval legs)")
-    ap.add_argument("--gemm", choices=["fp32", "bf16"], default="fp32",
+    ap.add_argument("--gemm", choices=["fp32", "fp32-mfma", "bf16"], default="fp32",
                     help="matrix-core operand precision (nr_set_gemm_compute): bf16 is the 1e-2-parity build of SURVEY §8 a7, "
                          "an extra measurement next to the fp32 headline")
     ap.add_argument("--repeats", type=int, default=4, help="extra timed regions of --steps steps after the headline one (min/median reported)")

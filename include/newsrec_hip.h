@@ -48,7 +48,13 @@ int nr_prof_enable(int on);
 int nr_prof_read(int family, double* ms, int64_t* launches, double* work);
 
 /* ---- matrix-core precision of the GEMM family -------------------------------------------
- * mode 0 (default): exact fp32 MFMA (the 1e-5 parity bar).  mode 1: operands rounded to bf16 on their way into
+ * mode 2 (default): fp32 results on the bf16 matrix pipe.  Each fp32 operand is split on its way into LDS into three
+ * bf16 pieces (a = a0 + a1 + a2, all 24 significand bits) and a*b is accumulated in fp32 from the six piece products of
+ * weight >= 2^-16; the dropped ones are below fp32's own rounding of the product, so the result has fp32 accuracy
+ * (the 1e-5 parity bar, same tests) at 1.3-1.6x the rate of the fp32 instruction.  Products too small to fill the chip
+ * with the kernel's 16 384-element tiles run as in mode 0.
+ * mode 0: every product on the fp32 matrix instruction (v_mfma_f32_32x32x2_f32, an exact fp32 fma chain).
+ * mode 1: operands rounded to bf16 on their way into
  * LDS, f32 accumulate (v_mfma_f32_32x32x16_bf16) for every product with M, N, K >= 128 (conv views included); tensors in HBM
  * stay fp32.  This is the "bf16-MFMA build" of SURVEY §8 a7 (AllBertNewsEncoder, encoder.py:62-77; parity bar
  * 1e-2); the closest thing in the reference is running the model under torch.autocast.  Process-wide and sticky:

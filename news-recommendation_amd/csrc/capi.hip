@@ -145,7 +145,7 @@ extern "C" {
 
 int nr_version(void) { return 1; }
 int nr_set_gemm_compute(int mode) {
-    NR_CHECK_ARG(mode == 0 || mode == 1, "nr_set_gemm_compute: mode must be 0 (fp32) or 1 (bf16 operands)");
+    NR_CHECK_ARG(mode == 0 || mode == 1 || mode == 2, "nr_set_gemm_compute: mode must be 0 (fp32 instruction), 1 (bf16 operands) or 2 (fp32 from three bf16 pieces)");
     nr::set_gemm_compute(mode);
     return NR_OK;
 }

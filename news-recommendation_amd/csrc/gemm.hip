@@ -31,6 +31,7 @@
 #include "gemm.h"
 #include <atomic>
 #include <cstdlib>
+#include <type_traits>
 
 namespace nr {
 
@@ -835,7 +836,402 @@ static int launch_bf16(const GemmParams& p, hipStream_t s) {
     return check_launch("gemm_bf16");
 }
 
-static std::atomic<int> g_gemm_compute{0};
+// =================================================================================================
+// fp32 products on the bf16 matrix pipe ("x3"): every fp32 operand is split on its way into LDS into three bf16 pieces
+//   a = a0 + a1 + a2,  a0 = bf16(a), a1 = bf16(a - a0), a2 = bf16(a - a0 - a1)        (both subtractions exact in fp32)
+// which together carry all 24 significand bits, and a*b is accumulated in fp32 from the six piece products of weight
+// >= 2^-16:  a0*b2 + a2*b0 + a1*b1 + a0*b1 + a1*b0 + a0*b0  (smallest first).  Each bf16 x bf16 product is exact in
+// fp32; the three dropped products (a1*b2, a2*b1, a2*b2) are below 2^-23 |a*b|, the size of fp32's own rounding of
+// the product.  v_mfma_f32_32x32x16_bf16 retires 8x the multiply-adds per cycle of v_mfma_f32_32x32x2_f32, so six
+// of them per k-step still run 2.7x faster than the fp32 instruction while the result keeps fp32 accuracy (the parity
+// tests hold this path to the same 1e-5 as the fp32 MFMA kernel).  Same operands in HBM (fp32), layouts, conv views,
+// epilogues, split-K and fused column sums as gemm_f32_kernel; loaders / LDS layout of gemm_bf16_kernel above, with
+// three planes per operand.  Workgroup tile (64*WM) x (64*NJ) x 32, 4 waves 2x2, ONE LDS stage with the next k-tile
+// prefetched into registers: 46-61 KB per workgroup leaves room for 2-3 workgroups per CU, whose waves keep the matrix
+// pipe busy while this one splits and stores its next tile.
+// LDS image of the x3 kernel: rows of exactly 32 bf16 (64 B, no padding), 16-byte chunk q of row r stored at chunk
+// q ^ ((r >> 2) & 3).  By the bank model of MI355X_MICROARCH.md (LDS table) that makes the ds_read_b128 fragment reads
+// and the ds_write_b64 staging stores conflict-free (the padded 80-byte rows of the bf16 kernel above cost 2x on both:
+// SQ_LDS_BANK_CONFLICT was half of SQ_LDS_IDX_ACTIVE).
+constexpr int X3_LD = 32;
+__device__ __forceinline__ int x3_swz(int row) { return (row >> 2) & 3; }
+
+template <int ROWS>
+struct LoaderKCX {
+    static constexpr int NP = ROWS / 32;
+    const float* base;             // first row of the tile (uniform)
+    uint32_t off[NP];              // byte offset of this thread's float4 in pass i (row clamped into the tensor)
+    unsigned valid, first, last;
+    int c4;
+    const float* safe;
+    __device__ __forceinline__ void init(const float* base_, int64_t ld, int row0, int nrows, int tid, int convT, const float* safe_) {
+        c4 = (tid & 7) * 4;
+        safe = safe_;
+        base = base_ + (int64_t)row0 * ld;
+        valid = first = last = 0;
+#pragma unroll
+        for (int i = 0; i < NP; ++i) {
+            const int r = row0 + (tid >> 3) + 32 * i;
+            const bool ok = r < nrows;
+            off[i] = (uint32_t)((ok ? r - row0 : 0) * (int)ld + c4) * 4u;
+            if (ok) valid |= 1u << i;
+            if (convT > 0) {
+                const int t = r % convT;
+                if (t == 0) first |= 1u << i;
+                if (t == convT - 1) last |= 1u << i;
+            }
+        }
+    }
+    // a full k-tile of a plain (non-conv) operand: rows past the edge read a clamped (valid) row, whose products only
+    // reach output rows / columns that are never stored -> no predication, wave-uniform base + 32-bit lane offset
+    __device__ __forceinline__ void load_full(f32x4 (&r)[NP], int k0) const {
+        const char* kb = reinterpret_cast<const char*>(base + k0);                  // uniform
+#pragma unroll
+        for (int i = 0; i < NP; ++i) r[i] = ldg4(kb + off[i]);
+    }
+    __device__ __forceinline__ void load(f32x4 (&r)[NP], int k0, int K, int convE) const {
+        const int k = k0 + c4;
+        const bool kok = k < K;
+        const unsigned dead = (k < convE ? first : 0u) | ((convE > 0 && k >= 2 * convE) ? last : 0u);
+        const unsigned live = kok ? (valid & ~dead) : 0u;
+        const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+        const char* kb = reinterpret_cast<const char*>(base + k0);                  // uniform
+        const char* sf = reinterpret_cast<const char*>(safe);
+#pragma unroll
+        for (int i = 0; i < NP; ++i) {
+            const bool o = (live >> i) & 1u;
+            const f32x4 v = ldg4(o ? kb + off[i] : sf);
+            r[i] = o ? v : z;
+        }
+    }
+};
+
+// two floats -> their three packed bf16 pieces
+#ifndef NR_X3_EXP
+#define NR_X3_EXP 0
+#endif
+#ifndef NR_X3_WGS
+#define NR_X3_WGS 2
+#endif
+__device__ __forceinline__ void split3(float x, float y, uint32_t& p0, uint32_t& p1, uint32_t& p2) {
+#if NR_X3_EXP == 1
+    p0 = __builtin_amdgcn_perm(__float_as_uint(y), __float_as_uint(x), 0x07060302u);
+    p1 = p0; p2 = p0;
+    return;
+#endif
+    p0 = pack_bf16(x, y);
+    float rx = x - __uint_as_float(p0 << 16), ry = y - __uint_as_float(p0 & 0xffff0000u);
+    p1 = pack_bf16(rx, ry);
+    rx -= __uint_as_float(p1 << 16);
+    ry -= __uint_as_float(p1 & 0xffff0000u);
+    p2 = pack_bf16(rx, ry);
+}
+
+template <int ROWS>
+__device__ __forceinline__ void store_kc_x3(uint32_t* lds, const f32x4 (&r)[ROWS / 32], int tid) {
+    constexpr int PL = ROWS * X3_LD / 2;                  // dwords per plane
+    const int q = (tid & 7) >> 1, half = (tid & 1) * 2, row0 = tid >> 3;
+#pragma unroll
+    for (int i = 0; i < ROWS / 32; ++i) {
+        const int row = row0 + 32 * i;
+        uint2 v0, v1, v2;
+        split3(r[i][0], r[i][1], v0.x, v1.x, v2.x);
+        split3(r[i][2], r[i][3], v0.y, v1.y, v2.y);
+        uint32_t* d = lds + row * (X3_LD / 2) + 4 * (q ^ x3_swz(row)) + half;
+        *reinterpret_cast<uint2*>(d) = v0;
+        *reinterpret_cast<uint2*>(d + PL) = v1;
+        *reinterpret_cast<uint2*>(d + 2 * PL) = v2;
+    }
+}
+
+// reduction-major 32 (k) x COLS tile, COLS = 64 | 128 | 256: one wave instruction covers 32 columns x 8 k pairs (lane =
+// 8*c + a: columns 4*a .. +3 of the group, k pair c of the half).  The COLS/16 (column group, k half) units are dealt
+// round-robin to the waves: unit u = w + 4*i -> column group u % (COLS/32), k half u / (COLS/32).
+template <int COLS>
+struct LoaderRMX {
+    static constexpr int NP = COLS / 64;                  // units (k pairs) per thread
+    static constexpr int NG = COLS / 32;
+    const float* base;
+    int64_t ld;
+    int w, a, c, col0, ncols;
+    const float* safe;
+    __device__ __forceinline__ void init(const float* base_, int64_t ld_, int col0_, int ncols_, int tid, const float* safe_) {
+        base = base_; ld = ld_; safe = safe_; col0 = col0_; ncols = ncols_;
+        w = __builtin_amdgcn_readfirstlane(tid >> 6);
+        const int lane = tid & 63;
+        a = lane & 7;
+        c = lane >> 3;
+    }
+    __device__ __forceinline__ int lrow(int i) const { return 32 * ((w + 4 * i) % NG) + 4 * a; }      // tile-local first column
+    __device__ __forceinline__ int kp(int i) const { return 8 * ((w + 4 * i) / NG) + c; }             // k pair inside the k-tile
+    __device__ __forceinline__ bool conv_dead(int k, int col, int convT, int convE) const {
+        if (convT <= 0) return false;
+        const int t = k % convT;
+        return (t == 0 && col < convE) || (t == convT - 1 && col >= 2 * convE);
+    }
+    __device__ __forceinline__ void load_full(f32x4 (&r)[2 * NP], int k0) const {
+        const uint32_t rowb = (uint32_t)ld * 4u;
+#pragma unroll
+        for (int i = 0; i < NP; ++i) {
+            const int khalf = (w + 4 * i) / NG;                                                      // uniform
+            const char* kb = reinterpret_cast<const char*>(base + (int64_t)(k0 + 16 * khalf) * ld);
+            const int col = col0 + lrow(i);
+            const uint32_t off = (uint32_t)(2 * c * (int)ld + (col < ncols ? col : col0)) * 4u;
+            r[2 * i] = ldg4(kb + off);
+            r[2 * i + 1] = ldg4(kb + off + rowb);
+        }
+    }
+    __device__ __forceinline__ void load(f32x4 (&r)[2 * NP], int k0, int K, int convT, int convE) const {
+        const uint32_t rowb = (uint32_t)ld * 4u;
+        const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+        const char* sf = reinterpret_cast<const char*>(safe);
+#pragma unroll
+        for (int i = 0; i < NP; ++i) {
+            const int khalf = (w + 4 * i) / NG;                                                      // uniform
+            const char* kb = reinterpret_cast<const char*>(base + (int64_t)(k0 + 16 * khalf) * ld);
+            const int col = col0 + lrow(i);
+            const bool cvalid = col < ncols;
+            const uint32_t off = (uint32_t)(2 * c * (int)ld + (cvalid ? col : col0)) * 4u;
+            const int k = k0 + 2 * kp(i);
+            const bool o0 = cvalid && k < K && !conv_dead(k, col, convT, convE), o1 = cvalid && k + 1 < K && !conv_dead(k + 1, col, convT, convE);
+            const f32x4 v0 = ldg4(o0 ? kb + off : sf), v1 = ldg4(o1 ? kb + off + rowb : sf);
+            r[2 * i] = o0 ? v0 : z;
+            r[2 * i + 1] = o1 ? v1 : z;
+        }
+    }
+};
+template <int COLS>
+__device__ __forceinline__ void store_rm_x3(uint32_t* lds, const f32x4 (&r)[COLS / 32], const LoaderRMX<COLS>& L) {
+    constexpr int PL = COLS * X3_LD / 2;
+#pragma unroll
+    for (int i = 0; i < COLS / 64; ++i) {
+        const int lrow = L.lrow(i), kp = L.kp(i);
+        const int sw = x3_swz(lrow);                      // rows lrow .. lrow+3 (lrow a multiple of 4) share the swizzle
+        uint32_t* d = lds + lrow * (X3_LD / 2) + 4 * ((kp >> 2) ^ sw) + (kp & 3);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            uint32_t p0, p1, p2;
+            split3(r[2 * i][j], r[2 * i + 1][j], p0, p1, p2);
+            d[j * (X3_LD / 2)] = p0;
+            d[j * (X3_LD / 2) + PL] = p1;
+            d[j * (X3_LD / 2) + 2 * PL] = p2;
+        }
+    }
+}
+
+// WR x WC waves (WR * WC = 4), each owning a 64 x 64 block (2 x 2 MFMA tiles): per k-step of 16 a wave reads 12 LDS
+// fragments (2 row blocks + 2 column blocks, 3 pieces each) for its 24 MFMAs.  LDS bandwidth is what this kernel is
+// bounded by next to the matrix pipe (a 64 x 32 wave block needs 9 fragments per 12 MFMAs and ran LDS-bound, 95-115
+// TFLOP/s), hence the square wave block and the tile shapes 256 x 64 / 128 x 128 / 64 x 256 around it.
+template <bool A_KC, bool B_KC, int WR, int WC>
+__global__ __launch_bounds__(256, NR_X3_WGS) void gemm_x3_kernel(const GemmParams p) {
+    constexpr int BM = 64 * WR, BN = 64 * WC;
+    constexpr int PA = BM * X3_LD / 2, PB = BN * X3_LD / 2;           // dwords per plane
+    constexpr int NA = BM / 32, NB = BN / 32;                          // staging f32x4 per thread
+    extern __shared__ __attribute__((aligned(16))) uint32_t smem_x3[]; // A planes 0..2, B planes 0..2
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wid / WC, wc = wid % WC;
+    const int l31 = lane & 31, h = lane >> 5;
+
+    const int tiles_n = (p.N + BN - 1) / BN;
+    const int tiles_m = (p.M + BM - 1) / BM;
+    const int ntile = tiles_m * tiles_n;
+    int bid = blockIdx.x;
+    {                                       // slice-major over the whole grid (see gemm_f32_kernel)
+        const int G = ntile * p.ksplit;
+        const int q = G >> 3, r = G & 7, x = bid & 7, loc = bid >> 3;
+        bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + loc;
+    }
+    const int ks = bid / ntile;
+    bid -= ks * ntile;
+    const int tm = bid / tiles_n, tn = bid - tm * tiles_n;
+    const int m0 = tm * BM, n0 = tn * BN;
+
+    const int kt_total = (p.K + BK - 1) / BK;
+    const int kt_per = (kt_total + p.ksplit - 1) / p.ksplit;
+    const int kt_begin = ks * kt_per;
+    const int kt_end = min(kt_total, kt_begin + kt_per);
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    f32x4 ra[NA], rb[NB];                                  // the next k-tile on its way HBM -> LDS
+    LoaderKCX<BM> lkA; LoaderKCX<BN> lkB; LoaderRMX<BM> lrA; LoaderRMX<BN> lrB;
+    const int convA = (A_KC && p.conv_on == 1) ? p.conv_T : 0;
+    const int convB = (!B_KC && p.conv_on == 2) ? p.conv_T : 0;
+    const float* safeA = p.A + (convA ? p.conv_E : 0);
+    const float* safeB = p.B + (convB ? p.conv_E : 0);
+    if (A_KC) lkA.init(p.A, p.lda, m0, p.M, tid, convA, safeA); else lrA.init(p.A, p.lda, m0, p.M, tid, safeA);
+    if (B_KC) lkB.init(p.B, p.ldb, n0, p.N, tid, 0, safeB);     else lrB.init(p.B, p.ldb, n0, p.N, tid, safeB);
+
+    // bias gradient riding on dW (A reduction-major): exact fp32 column sums of the A tile from the staging registers,
+    // one partial per unit of the loader
+    const bool do_csum = !A_KC && p.csum != nullptr && tn == 0;
+    f32x4 cs[A_KC ? 1 : BM / 64];
+#pragma unroll
+    for (int i = 0; i < (A_KC ? 1 : BM / 64); ++i) cs[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const bool plain = p.conv_on == 0;
+    const int kt_fullk = p.K / BK;                         // k-tiles below this index are complete
+    auto gload = [&](int kt) {
+        const int k0 = kt * BK;
+        if (plain && kt < kt_fullk) {                      // uniform: no predication, clamped rows (see load_full)
+            if (A_KC) lkA.load_full(ra, k0); else lrA.load_full(ra, k0);
+            if (B_KC) lkB.load_full(rb, k0); else lrB.load_full(rb, k0);
+        } else {
+            if (A_KC) lkA.load(ra, k0, p.K, convA ? p.conv_E : 0); else lrA.load(ra, k0, p.K, 0, 0);
+            if (B_KC) lkB.load(rb, k0, p.K, 0);                    else lrB.load(rb, k0, p.K, convB, p.conv_E);
+        }
+    };
+    auto lstore = [&]() {
+        uint32_t* As = smem_x3;
+        uint32_t* Bs = As + 3 * PA;
+        if constexpr (A_KC) store_kc_x3<BM>(As, ra, tid);
+        else {
+            store_rm_x3<BM>(As, ra, lrA);
+            if (do_csum) {
+#pragma unroll
+                for (int i = 0; i < BM / 64; ++i) cs[i] += ra[2 * i] + ra[2 * i + 1];
+            }
+        }
+        if constexpr (B_KC) store_kc_x3<BN>(Bs, rb, tid); else store_rm_x3<BN>(Bs, rb, lrB);
+    };
+
+    struct Frags { bf16x8 a[2][3]; bf16x8 b[2][3]; };
+    const int frag_sw = x3_swz(l31);                      // tile bases are multiples of 32 rows
+    auto fload = [&](Frags& f, int s) {
+        const uint32_t* As = smem_x3;
+        const uint32_t* Bs = As + 3 * PA;
+        const int q4 = 4 * ((2 * s + h) ^ frag_sw);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int t = 0; t < 3; ++t)
+                f.a[i][t] = *reinterpret_cast<const bf16x8*>(As + t * PA + (wr * 64 + i * 32 + l31) * (X3_LD / 2) + q4);
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int t = 0; t < 3; ++t)
+                f.b[j][t] = *reinterpret_cast<const bf16x8*>(Bs + t * PB + (wc * 64 + j * 32 + l31) * (X3_LD / 2) + q4);
+    };
+    auto fmma = [&](const Frags& f) {
+        constexpr int TA[6] = {0, 2, 1, 0, 1, 0}, TB[6] = {2, 0, 1, 1, 0, 0};      // smallest products first
+#pragma unroll
+        for (int t = (NR_X3_EXP == 2 ? 5 : 0); t < 6; ++t)
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[i][TA[t]], f.b[j][TB[t]], acc[i][j], 0, 0, 0);
+    };
+
+    // ONE LDS stage with the next k-tile prefetched into registers (the single-buffer loop of gemm_f32_kernel): 49-61 KB
+    // of LDS and <= 168 VGPRs leave room for 2-3 workgroups per CU.  With K = 300 (ten k-tiles) a workgroup is mostly
+    // prologue and epilogue, which only other resident workgroups can cover: a two-stage, one-workgroup-per-CU pipeline
+    // measured slower on every NRMS shape (and no faster at 4096^3, where the k-loop waits on L2 either way).
+    const int nkt = kt_end - kt_begin;
+    if (nkt > 0) {
+        gload(kt_begin);
+        lstore();
+    }
+    __syncthreads();
+    for (int kt = kt_begin; kt < kt_end; ++kt) {
+        const bool more = kt + 1 < kt_end;
+#if NR_X3_WGS >= 3
+        Frags f0;                                          // 168 VGPRs: one fragment set at a time
+        fload(f0, 0);
+        if (more) gload(kt + 1);
+        fmma(f0);
+        fload(f0, 1);
+        fmma(f0);
+#else
+        Frags f0, f1;
+        fload(f0, 0);
+        if (more) gload(kt + 1);
+        fload(f1, 1);
+        fmma(f0);
+        fmma(f1);
+#endif
+        __syncthreads();                                  // everyone is done reading the single stage
+        if (more) lstore();
+        __syncthreads();
+    }
+    if (do_csum) {
+        // lanes that share 4 columns (same a, all c) meet by shuffles, the units of one column group (two k halves, on
+        // one or two waves) through LDS: two addends per slot on top of 0 -> order-independent
+        float* dst = p.ksplit > 1 ? p.csum_part + (int64_t)ks * p.M : p.csum;
+        float* red = reinterpret_cast<float*>(smem_x3);
+        for (int x = tid; x < BM; x += 256) red[x] = 0.f;
+        __syncthreads();
+        if constexpr (!A_KC) {
+#pragma unroll
+            for (int i = 0; i < BM / 64; ++i) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    float v = cs[i][j];
+                    v += __shfl_xor(v, 8);
+                    v += __shfl_xor(v, 16);
+                    v += __shfl_xor(v, 32);
+                    if ((lane >> 3) == 0) atomicAdd(&red[lrA.lrow(i) + j], v);
+                }
+            }
+        }
+        __syncthreads();
+        for (int x = tid; x < BM; x += 256)
+            if (m0 + x < p.M) dst[m0 + x] = red[x];
+    }
+
+    const bool partial = p.ksplit > 1;
+    float* Cout = partial ? p.C + (int64_t)ks * p.split_stride : p.C;
+    const int mw = m0 + wr * 64, nw = n0 + wc * 64;
+    const bool full = (mw + 64 <= p.M) && (nw + 64 <= p.N);
+    const bool ub = !partial && p.bias != nullptr;
+    const int epi = partial ? EPI_NONE : p.epi;
+    if (full) store_block_rt<2, 2, false>(acc, Cout, mw, nw, l31, h, ub, epi, p);
+    else      store_block_rt<2, 2, true>(acc, Cout, mw, nw, l31, h, ub, epi, p);
+}
+
+template <bool A_KC, bool B_KC, int WR, int WC>
+static int launch_x3(const GemmParams& p, hipStream_t s) {
+    constexpr int BM = 64 * WR, BN = 64 * WC;
+    constexpr size_t lds = 3 * (BM + BN) * X3_LD * 2;
+    static bool once = [] {                               // > 64 KB of dynamic LDS needs the opt-in
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_x3_kernel<A_KC, B_KC, WR, WC>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        return true;
+    }();
+    (void)once;
+    const int tiles = cdiv(p.M, BM) * cdiv(p.N, BN);
+    hipLaunchKernelGGL((gemm_x3_kernel<A_KC, B_KC, WR, WC>), dim3(tiles * p.ksplit), dim3(256), lds, s, p);
+    return check_launch("gemm_x3");
+}
+// shape: 0 = 256 x 64, 1 = 128 x 128, 2 = 64 x 256
+template <bool A_KC, bool B_KC>
+static int launch_x3_tile(const GemmParams& p, int shape, hipStream_t s) {
+    if (shape == 0) return launch_x3<A_KC, B_KC, 4, 1>(p, s);
+    if (shape == 2) return launch_x3<A_KC, B_KC, 1, 4>(p, s);
+    return launch_x3<A_KC, B_KC, 2, 2>(p, s);
+}
+static int x3_tile_shape(int M, int N) {
+    // the shape that pads least (ties: the square one)
+    int64_t best = -1; int shape = 1;
+    const int bm[3] = {256, 128, 64}, bn[3] = {64, 128, 256}, order[3] = {1, 0, 2};
+    for (int o = 0; o < 3; ++o) {
+        const int t = order[o];
+        const int64_t area = (int64_t)cdiv(M, bm[t]) * bm[t] * cdiv(N, bn[t]) * bn[t];
+        if (best < 0 || area < best) { best = area; shape = t; }
+    }
+    return shape;
+}
+
+static std::atomic<int> g_gemm_compute{2};       // default: fp32 results from split operands on the bf16 matrix pipe
 void set_gemm_compute(int mode) { g_gemm_compute.store(mode); }
 int get_gemm_compute() { return g_gemm_compute.load(); }
 
@@ -971,10 +1367,23 @@ int gemm_f32(GemmParams p, bool a_kc, bool b_kc, float* workspace, size_t ws_byt
     // bf16-input matrix cores when the caller asked for them (nr_set_gemm_compute(1)) and the product is big enough
     // to matter; small products stay on the exact fp32 kernel
     const bool half = g_gemm_compute.load() == 1 && p.M >= 128 && p.N >= 128 && p.K >= 128;
+    // mode 2: fp32 products from three bf16 pieces per operand (gemm_x3_kernel) wherever its 16 384-element tiles fill
+    // the chip; small products (the user tower: 1 600 rows) stay on the fp32 instruction and its 64-row tiles
+    static const int env_shape = getenv("NR_X3_SHAPE") ? atoi(getenv("NR_X3_SHAPE")) : -1;       // A/B switches for tools
+    static const int env_minwg = getenv("NR_X3_MIN_WGS") ? atoi(getenv("NR_X3_MIN_WGS")) : 200;
+    const int x3_shape = env_shape >= 0 ? env_shape : x3_tile_shape(p.M, p.N);
+    const int x3_bm[3] = {256, 128, 64}, x3_bn[3] = {64, 128, 256};
+    const bool x3 = g_gemm_compute.load() == 2 && p.K >= 64 && (a_kc || !b_kc) &&
+                    (int64_t)cdiv(p.M, x3_bm[x3_shape]) * cdiv(p.N, x3_bn[x3_shape]) * p.ksplit >= env_minwg;
     if (half) {
         if (a_kc && b_kc)        rc = launch_bf16<true, true>(q, s);
         else if (a_kc && !b_kc)  rc = launch_bf16<true, false>(q, s);
         else                     rc = launch_bf16<false, false>(q, s);
+    } else if (x3) {
+        const int shape = x3_shape;
+        if (a_kc && b_kc)        rc = launch_x3_tile<true, true>(q, shape, s);
+        else if (a_kc && !b_kc)  rc = launch_x3_tile<true, false>(q, shape, s);
+        else                     rc = launch_x3_tile<false, false>(q, shape, s);
     } else {
     // BN=128 only when it wastes no more columns than BN=64
     // BN=128 only when it pads no more columns than BN=64: at N=1200 (6.7 % vs 1.3 % padding) the wide tile measured

@@ -998,14 +998,21 @@ def prof_read(family):
 
 
 # ----------------------------------------------------------------------------- GEMM precision
+_GEMM_MODES = {"fp32": 2, "bf16": 1, "fp32-mfma": 0}
+
+
 def set_gemm_compute(mode):
-    """"fp32" (default: exact f32 matrix cores) or "bf16" (operands rounded to bf16 in LDS, f32 accumulate, large
-    non-conv products only; the 1e-2 parity bar of SURVEY §8 a7).  Process-wide and sticky."""
-    modes = {"fp32": 0, "bf16": 1}
-    if mode not in modes:
-        raise NewsrecError(f"set_gemm_compute: unknown mode {mode!r} (fp32 | bf16)")
-    check(lib().nr_set_gemm_compute(modes[mode]), "nr_set_gemm_compute")
+    """how the large dense products are computed (process-wide, sticky; nr_set_gemm_compute):
+      "fp32"       the default.  f32 results from three bf16 pieces per operand on the bf16 matrix pipe (gemm_x3_kernel):
+                   f32 accuracy, the 1e-5 parity bar, 1.3-1.6x the rate of the f32 matrix instruction; products too small
+                   to fill the chip with its tiles stay on that instruction
+      "fp32-mfma"  every product on the f32 matrix instruction (v_mfma_f32_32x32x2_f32), the round-1 path
+      "bf16"       operands rounded to bf16, f32 accumulate: the 1e-2 parity bar of SURVEY §8 a7"""
+    if mode not in _GEMM_MODES:
+        raise NewsrecError(f"set_gemm_compute: unknown mode {mode!r} ({' | '.join(_GEMM_MODES)})")
+    check(lib().nr_set_gemm_compute(_GEMM_MODES[mode]), "nr_set_gemm_compute")
 
 
 def get_gemm_compute():
-    return ("fp32", "bf16")[lib().nr_get_gemm_compute()]
+    v = lib().nr_get_gemm_compute()
+    return next(k for k, m in _GEMM_MODES.items() if m == v)

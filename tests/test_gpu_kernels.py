@@ -58,11 +58,23 @@ def test_gather_multi_dim_ids_and_grad(ops):
     assert t_gpu.grad[0].abs().max().item() == 0.0
 
 
-# ------------------------------------------------------------------ dense layers (f32 MFMA GEMM)
+# ------------------------------------------------------------------ dense layers (f32 GEMMs)
+@pytest.fixture(params=["fp32", "fp32-mfma"])
+def f32_gemm(request, ops):
+    """both fp32-accuracy GEMM modes: "fp32" (the default: split-operand kernel on the bf16 matrix pipe for products
+    that fill the chip, the f32 instruction below that) and "fp32-mfma" (the f32 instruction everywhere) — same bar"""
+    ops.set_gemm_compute(request.param)
+    assert ops.get_gemm_compute() == request.param
+    yield ops
+    ops.set_gemm_compute("fp32")
+
+
 @pytest.mark.parametrize("R,K,N", [(1760 * 4, 300, 900), (1600, 300, 1200), (1280, 1200, 300), (130, 768, 768),
+                                   (19936, 300, 1200), (20001, 100, 77), (16000, 1200, 300),       # split-operand kernel: all three tile shapes, ragged M / N / K
                                    (37, 20, 24), (5, 24, 96), (300, 25, 30), (1, 4, 4)])
 @pytest.mark.parametrize("act", ["none", "relu", "gelu", "tanh"])
-def test_linear_forward(ops, R, K, N, act):
+def test_linear_forward(f32_gemm, R, K, N, act):
+    ops = f32_gemm
     g = G(3)
     x = torch.randn(R, K, generator=g)
     w = torch.randn(N, K, generator=g) / math.sqrt(K)
@@ -78,8 +90,9 @@ def test_linear_forward(ops, R, K, N, act):
 
 @pytest.mark.parametrize("R,K,N", [(1760 * 4, 300, 900), (3200, 1200, 300), (1600, 300, 1200), (200, 24, 24), (77, 20, 36),
                                    (64, 25, 10), (10000, 96, 288),      # tall dW tile, ragged K, empty split-K slices
-                                   (56320 // 4 + 20, 300, 300)])
-def test_linear_backward(ops, R, K, N):
+                                   (56320 // 4 + 20, 300, 300), (19936, 300, 1200), (19937, 1200, 300), (20001, 100, 76)])
+def test_linear_backward(f32_gemm, R, K, N):
+    ops = f32_gemm
     g = G(4)
     x = torch.randn(R, K, generator=g)
     w = torch.randn(N, K, generator=g) / math.sqrt(K)
@@ -178,6 +191,7 @@ def test_bf16_mode_leaves_small_products_exact(bf16_gemm):
     assert relerr(ops.linear_fwd(x.cuda(), w.cuda(), None, "none", None), x @ w.t()) < FP32_TOL
     with pytest.raises(Exception):
         ops.set_gemm_compute("fp8")
+    assert ops.get_gemm_compute() == "bf16"             # an unknown name changes nothing
 
 
 def test_linear_autograd_module(ops):
@@ -196,8 +210,9 @@ def test_linear_autograd_module(ops):
     assert relerr(wg.grad, lin.weight.grad) < FP32_TOL and relerr(bg.grad, lin.bias.grad) < FP32_TOL
 
 
-@pytest.mark.parametrize("M,T,E,D", [(440, 32, 768, 768), (55, 32, 300, 300), (7, 8, 24, 20), (3, 1, 8, 12), (2, 5, 6, 10)])
-def test_conv1d_k3_relu(ops, M, T, E, D):
+@pytest.mark.parametrize("M,T,E,D", [(440, 32, 768, 768), (1760, 32, 300, 300), (55, 32, 300, 300), (7, 8, 24, 20), (3, 1, 8, 12), (2, 5, 6, 10)])
+def test_conv1d_k3_relu(f32_gemm, M, T, E, D):
+    ops = f32_gemm
     g = G(6)
     x = torch.randn(M, T, E, generator=g)
     conv = torch.nn.Conv1d(E, D, 3, padding=1)

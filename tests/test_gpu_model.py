@@ -171,12 +171,25 @@ def _packed_case(N, S, D, H, seed, with_empty):
     return layer, x, lens, mask, dy
 
 
+@pytest.mark.parametrize("gemm", ["fp32-mfma", "fp32"])
 @pytest.mark.parametrize("N,S,D,H", [(64, 32, 300, 12), (1760, 32, 300, 12), (40, 32, 768, 12), (9, 17, 24, 4)])
-def test_packed_layer_equals_padded_layer(N, S, D, H):
+def test_packed_layer_equals_padded_layer(N, S, D, H, gemm):
     """packed title tokens (rows of padded positions removed) against the padded layout on the SAME kernels, train mode
     with dropout: the forward rows of real tokens are bit-identical (dropout keep-bits are indexed by the original
-    position), all-PAD titles keep their S rows, and every gradient agrees (split-K order differs: tolerance)."""
+    position), all-PAD titles keep their S rows, and every gradient agrees (split-K order differs: tolerance).
+    Bit-identical holds per GEMM kernel (a row's result does not depend on the tiling in either of them); in the
+    default mode the row count decides which kernel a product runs on, so a packed and a padded launch of the same
+    layer may differ in the last bits there (40 x 32 x 768: the 1280-row padded FFN fills the chip, the packed one does
+    not) and the forward is held to 2e-6 instead."""
     from newsrec_hip import ops
+    ops.set_gemm_compute(gemm)
+    try:
+        _packed_equals_padded(ops, N, S, D, H, exact=(gemm == "fp32-mfma"))
+    finally:
+        ops.set_gemm_compute("fp32")
+
+
+def _packed_equals_padded(ops, N, S, D, H, exact):
     layer, x, lens, mask, dy = _packed_case(N, S, D, H, 51, with_empty=True)
     keep = (torch.arange(S)[None] < torch.where(lens > 0, lens, torch.tensor(S))[:, None])
     layer = layer.cuda().train()
@@ -197,7 +210,10 @@ def test_packed_layer_equals_padded_layer(N, S, D, H):
     xp = x.view(-1, D)[row_map].cuda().requires_grad_(True)
     outp = ops.tfm_layer(xp, mask.cuda(), H, layer.kernel_params(), p, seed, site, plan=plan)
     outp.backward(dy.view(-1, D)[row_map].cuda())
-    assert torch.equal(outp, out.view(-1, D)[row_map.cuda()])
+    if exact:
+        assert torch.equal(outp, out.view(-1, D)[row_map.cuda()])
+    else:
+        assert relerr(outp, out.view(-1, D)[row_map.cuda()]) < 2e-6
     nonempty = (lens > 0)[:, None].expand(N, S).reshape(-1)[row_map].cuda()
     assert relerr(xp.grad[nonempty], xg.grad.view(-1, D)[row_map.cuda()][nonempty]) < GRAD_TOL
     assert relerr(xp.grad, xg.grad.view(-1, D)[row_map.cuda()]) < GRAD_TOL
@@ -245,10 +261,20 @@ def test_pack_refuses_non_prefix_masks():
     assert ops.pack_titles(torch.zeros(5, 8, dtype=torch.int64).cuda(), mask.cuda()) is not None
 
 
-def test_news_vectors_packed_equals_padded_encoder():
+@pytest.mark.parametrize("gemm", ["fp32-mfma", "fp32"])
+def test_news_vectors_packed_equals_padded_encoder(gemm):
     """TfmNewsEncoder.news_vectors (packed rows) == TfmNewsEncoder.forward()[1] (padded, the reference layout), eval and
-    train mode, incl. the all-PAD news and news without a title; gradients of both agree"""
+    train mode, incl. the all-PAD news and news without a title; gradients of both agree.  Bit-equal on one GEMM kernel
+    ("fp32-mfma"); in the default mode the row count picks the kernel per product, so 2e-6 there."""
     from newsrec_hip import ops
+    ops.set_gemm_compute(gemm)
+    try:
+        _news_vectors_packed_equals_padded(ops, (lambda a, b: torch.equal(a, b)) if gemm == "fp32-mfma" else (lambda a, b: relerr(a, b) < 2e-6))
+    finally:
+        ops.set_gemm_compute("fp32")
+
+
+def _news_vectors_packed_equals_padded(ops, same):
     meta = dict(V=30522, E=300, D=300, H=12, T=32, L=50, K=4, B=4, Nn=500)
     model, mgr = build_model(meta, "tfm", "tfm")
     g = torch.Generator().manual_seed(91)
@@ -259,7 +285,7 @@ def test_news_vectors_packed_equals_padded_encoder():
     with torch.no_grad():
         a = enc(ids_d, msk_d)[1]
         b = enc.news_vectors(ids_d, msk_d)
-    assert a.shape == b.shape == (5, 100, 300) and torch.equal(a, b)
+    assert a.shape == b.shape == (5, 100, 300) and same(a, b)
     enc.train()
     outs = []
     for fn in (lambda: enc(ids_d, msk_d)[1], lambda: enc.news_vectors(ids_d, msk_d)):
@@ -270,7 +296,7 @@ def test_news_vectors_packed_equals_padded_encoder():
         v.square().sum().backward()
         outs.append((v.detach().clone(), {n: p_.grad.clone() for n, p_ in enc.named_parameters()}))
     (va, ga), (vb, gb) = outs
-    assert torch.equal(va, vb)
+    assert same(va, vb)
     gscale = max(float(v.abs().max()) for v in ga.values())
     for n in ga:                                        # floor: key.bias gradients are analytically zero (rounding noise)
         assert (gb[n] - ga[n]).abs().max().item() <= GRAD_TOL * ga[n].abs().max().item() + 3e-6 * gscale, n
