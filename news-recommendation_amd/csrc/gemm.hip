@@ -576,15 +576,15 @@ __global__ __launch_bounds__(256, (WM * NJ <= 2) ? 4 : 2) void gemm_f32_kernel(c
 // bf16-input variant (v_mfma_f32_32x32x16_bf16, f32 accumulate): same operands in HBM (fp32), same
 // epilogues and split-K; the tiles are rounded to bf16 (RNE, v_cvt_pk_bf16_f32) on their way into LDS.
 // For the BERT-sized GEMMs whose parity bar is 1e-2.  Workgroup tile 128 x 128 x 32,
-// 4 waves 2x2, wave tile 64 x 64.  Both operands live in LDS k-contiguous as [row][32 + 8] bf16
-// (80-byte rows: 16-byte aligned and conflict-free for the ds_read_b128 of 8 consecutive k per lane);
+// 4 waves 2x2, wave tile 64 x 64.  Both operands live in LDS k-contiguous as [row][32] bf16
+// (64-byte rows, 16-byte chunks XOR-swizzled by row: hb_swz);
 // reduction-major operands are transposed while being stored: a thread loads two consecutive k-rows
 // of the same 4 columns and writes 4 packed (k, k+1) pairs, lanes laid out so the 64 writes of one
 // instruction hit 64 different banks.
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
-constexpr int HB_LD = 40;            // bf16 per LDS row
+constexpr int HB_LD = 32;            // bf16 per LDS row (64 B, unpadded: see hb_swz)
 
 __device__ __forceinline__ uint32_t pack_bf16(float lo, float hi) {
     const f32x2 v = {lo, hi};
@@ -632,10 +632,11 @@ struct LoaderKCH {
     }
 };
 
-// 16-byte chunk q (0..3) of row r sits at chunk q ^ hb_swz(r): rows 16..31 of every 32 swap their chunk pairs, which
-// is what makes the transposing stores below conflict-free; the b128 fragment reads stay conflict-free because the
-// 16 lanes of one read phase share the swizzle.
-__device__ __forceinline__ int hb_swz(int row) { return (row >> 3) & 2; }
+// 16-byte chunk q (0..3) of row r sits at chunk q ^ hb_swz(r).  With unpadded 64-byte rows and this swizzle the
+// ds_read_b128 fragment reads and the ds_write_b64 staging stores are conflict-free in the bank model of
+// MI355X_MICROARCH.md (lane groups of 16, 64 banks) and measured so (SQ_LDS_BANK_CONFLICT = 0); the round-1 layout
+// (80-byte rows, swizzle (r >> 3) & 2) cost 2x on both.
+__device__ __forceinline__ int hb_swz(int row) { return (row >> 2) & 3; }
 
 __device__ __forceinline__ void store_kc_bf16(uint32_t* lds, f32x4 r0, f32x4 r1, f32x4 r2, f32x4 r3, int tid) {
     const int q = (tid & 7) >> 1, half = (tid & 1) * 2, row0 = tid >> 3;
@@ -690,7 +691,7 @@ struct LoaderRMH {
 };
 __device__ __forceinline__ void store_rm_bf16(uint32_t* lds, f32x4 r0, f32x4 r1, f32x4 r2, f32x4 r3, int tid) {
     const int w = tid >> 6, lane = tid & 63, a = lane & 7, c = lane >> 3;
-    const int row = 32 * w + 4 * a;                       // rows row .. row+3 share bit 4 -> one swizzle
+    const int row = 32 * w + 4 * a;                       // rows row .. row+3 (row a multiple of 4) share the swizzle
     const int sw = hb_swz(row);
     uint32_t* d0 = lds + row * (HB_LD / 2) + 4 * ((c >> 2) ^ sw) + (c & 3);
     uint32_t* d1 = lds + row * (HB_LD / 2) + 4 * ((2 + (c >> 2)) ^ sw) + (c & 3);
@@ -851,7 +852,7 @@ static int launch_bf16(const GemmParams& p, hipStream_t s) {
 // pipe busy while this one splits and stores its next tile.
 // LDS image of the x3 kernel: rows of exactly 32 bf16 (64 B, no padding), 16-byte chunk q of row r stored at chunk
 // q ^ ((r >> 2) & 3).  By the bank model of MI355X_MICROARCH.md (LDS table) that makes the ds_read_b128 fragment reads
-// and the ds_write_b64 staging stores conflict-free (the padded 80-byte rows of the bf16 kernel above cost 2x on both:
+// and the ds_write_b64 staging stores conflict-free (padded 80-byte rows with the swizzle (r >> 3) & 2, the first layout, cost 2x on both:
 // SQ_LDS_BANK_CONFLICT was half of SQ_LDS_IDX_ACTIVE).
 constexpr int X3_LD = 32;
 __device__ __forceinline__ int x3_swz(int row) { return (row >> 2) & 3; }
@@ -1309,6 +1310,17 @@ size_t gemm_workspace_bytes(int M, int N, int ksplit) {
 }
 
 int choose_ksplit(int M, int N, int K) {
+    if (g_gemm_compute.load() == 2) {
+        // split-operand kernel: 9-25 tiles of 16 384 elements for the NRMS dW shapes -> slices until ~1.6 workgroups per
+        // CU are resident (its occupancy), never shorter than 8 k-tiles
+        static const int target = getenv("NR_X3_KS_WGS") ? atoi(getenv("NR_X3_KS_WGS")) : 416;      // A/B switch for tools (swept 200..1024 on the NRMS step: flat optimum 384-448)
+        const int shape = x3_tile_shape(M, N);
+        const int bm[3] = {256, 128, 64}, bn[3] = {64, 128, 256};
+        const int tiles = cdiv(M, bm[shape]) * cdiv(N, bn[shape]);
+        const int kt = cdiv(K, BK);
+        const int ks = std::min(cdiv(target, tiles), kt / 8);
+        if (ks >= 2 && tiles * ks >= 200) return ks;
+    }
     // dW GEMMs: tiny MxN, huge K.  Two pulls (swept on MI355X): enough workgroups to fill the
     // chip (>= 512), and slices of ~32 k-tiles — shorter slices than the fill needs only add slab traffic, longer
     // ones leave the single-buffered loop latency-bound (dW[1200,300]: 68 TF/s at 512 workgroups, 85 at 2048+)

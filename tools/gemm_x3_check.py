@@ -26,7 +26,7 @@ for name, K, N in [("qkv", 300, 900), ("outproj", 300, 300), ("ffn1", 300, 1200)
     line = f"{name:9s} R={Rr} K={K:4d} N={N:4d}"
     for tag in ("fwd", "dX", "dW"):
         fl = 2.0 * Rr * K * N
-        for mode in ("fp32", "fp32x3"):
+        for mode in ("fp32-mfma", "fp32"):
             ops.set_gemm_compute(mode)
             out = fns[tag]()
             out = out[0] if isinstance(out, tuple) else out
