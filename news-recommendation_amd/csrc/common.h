@@ -33,7 +33,7 @@ void set_error(const char* fmt, ...);
 int check_launch(const char* what);
 
 // optional per-family kernel timing (bench.py roofline leg); see prof.hip
-enum Family { FAM_GEMM = 0, FAM_GATHER, FAM_ATTN, FAM_LN, FAM_POOL, FAM_SCORE, FAM_MISC, FAM_SCATTER, FAM_COUNT };
+enum Family { FAM_GEMM = 0, FAM_GATHER, FAM_ATTN, FAM_LN, FAM_POOL, FAM_SCORE, FAM_MISC, FAM_SCATTER, FAM_GEMM_SPLIT, FAM_COUNT };
 void prof_begin(int family, hipStream_t s, double work);
 void prof_end(int family, hipStream_t s);
 

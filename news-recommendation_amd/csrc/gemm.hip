@@ -1353,7 +1353,15 @@ int gemm_f32(GemmParams p, bool a_kc, bool b_kc, float* workspace, size_t ws_byt
     if (p.ksplit < 1) p.ksplit = 1;
     const bool fast = gemm_fast_path(p, a_kc, b_kc);
     if (p.csum) NR_CHECK_ARG(fast && !a_kc && (p.ksplit <= 1 || p.csum_part), "gemm: fused column sums need the tiled reduction-major path");
-    ProfScope prof(FAM_GEMM, s, 2.0 * p.M * p.N * p.K);
+    // mode 2: fp32 products from three bf16 pieces per operand (gemm_x3_kernel) wherever its 16 384-element tiles fill
+    // the chip; small products (the user tower: 1 600 rows) stay on the fp32 instruction and its 64-row tiles
+    static const int env_shape = getenv("NR_X3_SHAPE") ? atoi(getenv("NR_X3_SHAPE")) : -1;       // A/B switches for tools
+    static const int env_minwg = getenv("NR_X3_MIN_WGS") ? atoi(getenv("NR_X3_MIN_WGS")) : 200;
+    const int x3_shape = env_shape >= 0 ? env_shape : x3_tile_shape(p.M, p.N);
+    const int x3_bm[3] = {256, 128, 64}, x3_bn[3] = {64, 128, 256};
+    const bool x3 = fast && g_gemm_compute.load() == 2 && p.K >= 64 && (a_kc || !b_kc) &&
+                    (int64_t)cdiv(p.M, x3_bm[x3_shape]) * cdiv(p.N, x3_bn[x3_shape]) * p.ksplit >= env_minwg;
+    ProfScope prof(x3 ? FAM_GEMM_SPLIT : FAM_GEMM, s, 2.0 * p.M * p.N * p.K);
     if (!fast) {
         p.ksplit = 1;
         const int64_t total = (int64_t)p.M * p.N;
@@ -1379,14 +1387,6 @@ int gemm_f32(GemmParams p, bool a_kc, bool b_kc, float* workspace, size_t ws_byt
     // bf16-input matrix cores when the caller asked for them (nr_set_gemm_compute(1)) and the product is big enough
     // to matter; small products stay on the exact fp32 kernel
     const bool half = g_gemm_compute.load() == 1 && p.M >= 128 && p.N >= 128 && p.K >= 128;
-    // mode 2: fp32 products from three bf16 pieces per operand (gemm_x3_kernel) wherever its 16 384-element tiles fill
-    // the chip; small products (the user tower: 1 600 rows) stay on the fp32 instruction and its 64-row tiles
-    static const int env_shape = getenv("NR_X3_SHAPE") ? atoi(getenv("NR_X3_SHAPE")) : -1;       // A/B switches for tools
-    static const int env_minwg = getenv("NR_X3_MIN_WGS") ? atoi(getenv("NR_X3_MIN_WGS")) : 200;
-    const int x3_shape = env_shape >= 0 ? env_shape : x3_tile_shape(p.M, p.N);
-    const int x3_bm[3] = {256, 128, 64}, x3_bn[3] = {64, 128, 256};
-    const bool x3 = g_gemm_compute.load() == 2 && p.K >= 64 && (a_kc || !b_kc) &&
-                    (int64_t)cdiv(p.M, x3_bm[x3_shape]) * cdiv(p.N, x3_bn[x3_shape]) * p.ksplit >= env_minwg;
     if (half) {
         if (a_kc && b_kc)        rc = launch_bf16<true, true>(q, s);
         else if (a_kc && !b_kc)  rc = launch_bf16<true, false>(q, s);
@@ -1397,7 +1397,6 @@ int gemm_f32(GemmParams p, bool a_kc, bool b_kc, float* workspace, size_t ws_byt
         else if (a_kc && !b_kc)  rc = launch_x3_tile<true, false>(q, shape, s);
         else                     rc = launch_x3_tile<false, false>(q, shape, s);
     } else {
-    // BN=128 only when it wastes no more columns than BN=64
     // BN=128 only when it pads no more columns than BN=64: at N=1200 (6.7 % vs 1.3 % padding) the wide tile measured
     // 9 489 vs 9 928 impressions/s on the whole step (r02 A/B), the extra columns cost more than the saved A re-reads
     const bool wide = (cdiv(p.N, 128) * 128 == cdiv(p.N, 64) * 64) && p.N >= 128;

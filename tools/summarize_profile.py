@@ -53,15 +53,16 @@ for k in set(fetch) | set(write) | set(mfma):
         # MFMA_BUSY sums the 1024 SIMDs; GRBM_GUI_ACTIVE sums the 8 XCDs
         d["mfma_busy_frac"] = round(sum(m["SQ_VALU_MFMA_BUSY_CYCLES"]) / 1024.0 / (sum(m["GRBM_GUI_ACTIVE"]) / 8.0), 4)
 
-gemm = {k: v for k, v in out.items() if "gemm_f32_kernel" in k}
-n = sum(v.get("calls", 0) for v in gemm.values())
 summary = {"tag": tag, "kernels": out}
-if n and all("hbm_bytes_per_launch" in v for v in gemm.values()):
-    summary["gemm_family"] = {
+for fam_name, pat in (("gemm_family", "gemm_f32_kernel"), ("gemm_split_family", "gemm_x3_kernel"), ("gemm_h_family", "gemm_h_kernel")):
+  gemm = {k: v for k, v in out.items() if pat in k}
+  n = sum(v.get("calls", 0) for v in gemm.values())
+  if n and all("hbm_bytes_per_launch" in v for v in gemm.values()):
+    summary[fam_name] = {
         "launches": n,
         "avg_us": round(sum(v["avg_us"] * v["calls"] for v in gemm.values()) / n, 2),
         "hbm_bytes_per_launch": int(sum(v["hbm_bytes_per_launch"] * v["calls"] for v in gemm.values()) / n),
         "mfma_busy_frac": round(sum(v.get("mfma_busy_frac", 0) * v["avg_us"] * v["calls"] for v in gemm.values()) /
                                 max(1e-9, sum(v["avg_us"] * v["calls"] for v in gemm.values())), 4)}
 json.dump(summary, open(os.path.join(root, "profiles", f"{tag}_counters.json"), "w"), indent=1, sort_keys=True)
-print(json.dumps(summary.get("gemm_family"), indent=1))
+print(json.dumps({k: v for k, v in summary.items() if k.endswith("_family")}, indent=1))
