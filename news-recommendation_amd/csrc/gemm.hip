@@ -1196,6 +1196,9 @@ __global__ __launch_bounds__(256, NR_X3_WGS) void gemm_x3_kernel(const GemmParam
     const bool full = (mw + 64 <= p.M) && (nw + 64 <= p.N);
     const bool ub = !partial && p.bias != nullptr;
     const int epi = partial ? EPI_NONE : p.epi;
+#if NR_X3_EXP == 3
+    if (acc[0][0][0] != 12345.678f) return;               // timing experiment: the k-loop without its epilogue
+#endif
     if (full) store_block_rt<2, 2, false>(acc, Cout, mw, nw, l31, h, ub, epi, p);
     else      store_block_rt<2, 2, true>(acc, Cout, mw, nw, l31, h, ub, epi, p);
 }
@@ -1230,6 +1233,344 @@ static int x3_tile_shape(int M, int N) {
         if (best < 0 || area < best) { best = area; shape = t; }
     }
     return shape;
+}
+
+// ---- the same arithmetic for products with few tiles (the user tower: 1 600 rows): ONE 64 x 64 block per workgroup,
+// shared by its four waves, which split every 64-deep k-tile between them (wave w takes the k-step 16*w .. 16*w+15) and
+// meet through LDS at the end.  25 x 5 tiles of a [1600, 300] product are 125 workgroups whose per-k-tile chain is a
+// quarter of the fp32 instruction kernel's (24 bf16 MFMAs = 768 cycles per wave and 64 k, against 32 x 64 cycles), and
+// three of them share a CU.  LDS image: rows of 64 bf16 (128 B), 16-byte chunk c of row r at c ^ ((r >> 1) & 7)
+// (conflict-free b128 fragment reads and b64 staging stores by the same bank model).
+constexpr int XS_BK = 64;
+constexpr int XS_LDW = 32;                                   // dwords per LDS row
+__device__ __forceinline__ int xs_swz(int row) { return (row >> 1) & 7; }
+
+struct LoaderKCS {                      // 64 rows x 64 k floats: thread loads f32x4 (row = t/16 + 16*i, k = (t%16)*4)
+    const float* base;
+    uint32_t off[4];
+    unsigned valid, first, last;
+    int c4;
+    const float* safe;
+    __device__ __forceinline__ void init(const float* base_, int64_t ld, int row0, int nrows, int tid, int convT, const float* safe_) {
+        c4 = (tid & 15) * 4;
+        safe = safe_;
+        base = base_ + (int64_t)row0 * ld;
+        valid = first = last = 0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int r = row0 + (tid >> 4) + 16 * i;
+            const bool ok = r < nrows;
+            off[i] = (uint32_t)((ok ? r - row0 : 0) * (int)ld + c4) * 4u;
+            if (ok) valid |= 1u << i;
+            if (convT > 0) {
+                const int t = r % convT;
+                if (t == 0) first |= 1u << i;
+                if (t == convT - 1) last |= 1u << i;
+            }
+        }
+    }
+    __device__ __forceinline__ void load_full(f32x4 (&r)[4], int k0) const {
+        const char* kb = reinterpret_cast<const char*>(base + k0);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) r[i] = ldg4(kb + off[i]);
+    }
+    __device__ __forceinline__ void load(f32x4 (&r)[4], int k0, int K, int convE) const {
+        const int k = k0 + c4;
+        const bool kok = k < K;
+        const unsigned dead = (k < convE ? first : 0u) | ((convE > 0 && k >= 2 * convE) ? last : 0u);
+        const unsigned live = kok ? (valid & ~dead) : 0u;
+        const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+        const char* kb = reinterpret_cast<const char*>(base + k0);
+        const char* sf = reinterpret_cast<const char*>(safe);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const bool o = (live >> i) & 1u;
+            const f32x4 v = ldg4(o ? kb + off[i] : sf);
+            r[i] = o ? v : z;
+        }
+    }
+};
+__device__ __forceinline__ void store_kc_xs(uint32_t* lds, const f32x4 (&r)[4], int tid) {
+    constexpr int PL = 64 * XS_LDW;
+    const int chunk = (tid & 15) >> 1, half = (tid & 1) * 2, row0 = tid >> 4;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int row = row0 + 16 * i;
+        uint2 v0, v1, v2;
+        split3(r[i][0], r[i][1], v0.x, v1.x, v2.x);
+        split3(r[i][2], r[i][3], v0.y, v1.y, v2.y);
+        uint32_t* d = lds + row * XS_LDW + 4 * (chunk ^ xs_swz(row)) + half;
+        *reinterpret_cast<uint2*>(d) = v0;
+        *reinterpret_cast<uint2*>(d + PL) = v1;
+        *reinterpret_cast<uint2*>(d + 2 * PL) = v2;
+    }
+}
+// reduction-major 64 (k) x 64 columns: lane = 8*c + a -> columns 32*(w&1) + 4*a .. +3, k pairs 8*((w>>1) + 2*i) + c, i = 0, 1
+struct LoaderRMS {
+    const float* base;
+    int64_t ld;
+    int w, a, c, col0, ncols;
+    const float* safe;
+    __device__ __forceinline__ void init(const float* base_, int64_t ld_, int col0_, int ncols_, int tid, const float* safe_) {
+        base = base_; ld = ld_; safe = safe_; col0 = col0_; ncols = ncols_;
+        w = __builtin_amdgcn_readfirstlane(tid >> 6);
+        const int lane = tid & 63;
+        a = lane & 7;
+        c = lane >> 3;
+    }
+    __device__ __forceinline__ int lrow() const { return 32 * (w & 1) + 4 * a; }
+    __device__ __forceinline__ int kp(int i) const { return 8 * ((w >> 1) + 2 * i) + c; }
+    __device__ __forceinline__ bool conv_dead(int k, int col, int convT, int convE) const {
+        if (convT <= 0) return false;
+        const int t = k % convT;
+        return (t == 0 && col < convE) || (t == convT - 1 && col >= 2 * convE);
+    }
+    __device__ __forceinline__ void load_full(f32x4 (&r)[4], int k0) const {
+        const uint32_t rowb = (uint32_t)ld * 4u;
+        const int col = col0 + lrow();
+        const uint32_t off = (uint32_t)(2 * c * (int)ld + (col < ncols ? col : col0)) * 4u;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const char* kb = reinterpret_cast<const char*>(base + (int64_t)(k0 + 16 * ((w >> 1) + 2 * i)) * ld);     // uniform
+            r[2 * i] = ldg4(kb + off);
+            r[2 * i + 1] = ldg4(kb + off + rowb);
+        }
+    }
+    __device__ __forceinline__ void load(f32x4 (&r)[4], int k0, int K, int convT, int convE) const {
+        const uint32_t rowb = (uint32_t)ld * 4u;
+        const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+        const char* sf = reinterpret_cast<const char*>(safe);
+        const int col = col0 + lrow();
+        const bool cvalid = col < ncols;
+        const uint32_t off = (uint32_t)(2 * c * (int)ld + (cvalid ? col : col0)) * 4u;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const char* kb = reinterpret_cast<const char*>(base + (int64_t)(k0 + 16 * ((w >> 1) + 2 * i)) * ld);
+            const int k = k0 + 2 * kp(i);
+            const bool o0 = cvalid && k < K && !conv_dead(k, col, convT, convE), o1 = cvalid && k + 1 < K && !conv_dead(k + 1, col, convT, convE);
+            const f32x4 v0 = ldg4(o0 ? kb + off : sf), v1 = ldg4(o1 ? kb + off + rowb : sf);
+            r[2 * i] = o0 ? v0 : z;
+            r[2 * i + 1] = o1 ? v1 : z;
+        }
+    }
+};
+__device__ __forceinline__ void store_rm_xs(uint32_t* lds, const f32x4 (&r)[4], const LoaderRMS& L) {
+    constexpr int PL = 64 * XS_LDW;
+    const int lrow = L.lrow();
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int kp = L.kp(i);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int row = lrow + j;
+            uint32_t p0, p1, p2;
+            split3(r[2 * i][j], r[2 * i + 1][j], p0, p1, p2);
+            uint32_t* d = lds + row * XS_LDW + 4 * ((kp >> 2) ^ xs_swz(row)) + (kp & 3);
+            d[0] = p0;
+            d[PL] = p1;
+            d[2 * PL] = p2;
+        }
+    }
+}
+
+template <bool A_KC, bool B_KC>
+__global__ __launch_bounds__(256, 2) void gemm_x3s_kernel(const GemmParams p) {
+    constexpr int PL = 64 * XS_LDW;                        // dwords per plane
+    __shared__ __attribute__((aligned(16))) uint32_t smem[6 * PL];   // A planes 0..2, B planes 0..2 (49 152 B); reused by the final exchange
+    uint32_t* As = smem;
+    uint32_t* Bs = smem + 3 * PL;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, h = lane >> 5;
+
+    const int tiles_n = (p.N + 63) / 64;
+    const int tiles_m = (p.M + 63) / 64;
+    const int ntile = tiles_m * tiles_n;
+    int bid = blockIdx.x;
+    {                                       // slice-major over the whole grid (see gemm_f32_kernel)
+        const int G = ntile * p.ksplit;
+        const int q = G >> 3, r = G & 7, x = bid & 7, loc = bid >> 3;
+        bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + loc;
+    }
+    const int ks = bid / ntile;
+    bid -= ks * ntile;
+    const int tm = bid / tiles_n, tn = bid - tm * tiles_n;
+    const int m0 = tm * 64, n0 = tn * 64;
+
+    const int kt_total = (p.K + XS_BK - 1) / XS_BK;
+    const int kt_per = (kt_total + p.ksplit - 1) / p.ksplit;
+    const int kt_begin = ks * kt_per;
+    const int kt_end = min(kt_total, kt_begin + kt_per);
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // THREE register sets: with 125 workgroups on 256 CUs nothing else hides a k-tile's load latency (one set: 19 k-tiles
+    // of a K = 1200 product cost 19 exposed L2/HBM round trips, 29 us), so the loads of tiles t+1 .. t+3 are in flight
+    // while tile t is multiplied.  Tile t travels through set t % 3; indices past the last tile are clamped (a redundant,
+    // unused load) so that the loop body has no branch around a load and every wait stays a counted one.
+    f32x4 ra[3][4], rb[3][4];
+    LoaderKCS lkA, lkB; LoaderRMS lrA, lrB;
+    const int convA = (A_KC && p.conv_on == 1) ? p.conv_T : 0;
+    const int convB = (!B_KC && p.conv_on == 2) ? p.conv_T : 0;
+    const float* safeA = p.A + (convA ? p.conv_E : 0);
+    const float* safeB = p.B + (convB ? p.conv_E : 0);
+    if (A_KC) lkA.init(p.A, p.lda, m0, p.M, tid, convA, safeA); else lrA.init(p.A, p.lda, m0, p.M, tid, safeA);
+    if (B_KC) lkB.init(p.B, p.ldb, n0, p.N, tid, 0, safeB);     else lrB.init(p.B, p.ldb, n0, p.N, tid, safeB);
+
+    const bool do_csum = !A_KC && p.csum != nullptr && tn == 0;
+    f32x4 cs = {0.f, 0.f, 0.f, 0.f};
+
+    const int nkt = kt_end - kt_begin;
+    auto gload = [&](auto set, int t) {
+        constexpr int S = decltype(set)::value;
+        const int k0 = (kt_begin + min(t, nkt - 1)) * XS_BK;
+        if (A_KC) lkA.load(ra[S], k0, p.K, convA ? p.conv_E : 0); else lrA.load(ra[S], k0, p.K, 0, 0);
+        if (B_KC) lkB.load(rb[S], k0, p.K, 0);                    else lrB.load(rb[S], k0, p.K, convB, p.conv_E);
+    };
+    auto lstore = [&](auto set) {
+        constexpr int S = decltype(set)::value;
+        if constexpr (A_KC) store_kc_xs(As, ra[S], tid);
+        else {
+            store_rm_xs(As, ra[S], lrA);
+            if (do_csum) cs += (ra[S][0] + ra[S][1]) + (ra[S][2] + ra[S][3]);
+        }
+        if constexpr (B_KC) store_kc_xs(Bs, rb[S], tid); else store_rm_xs(Bs, rb[S], lrB);
+    };
+    auto compute = [&]() {
+        bf16x8 fa[2][3], fb[2][3];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int row = i * 32 + l31;
+            const int q4 = 4 * ((2 * wid + h) ^ xs_swz(row));
+#pragma unroll
+            for (int t = 0; t < 3; ++t) {
+                fa[i][t] = *reinterpret_cast<const bf16x8*>(As + t * PL + row * XS_LDW + q4);
+                fb[i][t] = *reinterpret_cast<const bf16x8*>(Bs + t * PL + row * XS_LDW + q4);
+            }
+        }
+        constexpr int TA[6] = {0, 2, 1, 0, 1, 0}, TB[6] = {2, 0, 1, 1, 0, 0};      // smallest products first
+#pragma unroll
+        for (int t = 0; t < 6; ++t)
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][TA[t]], fb[j][TB[t]], acc[i][j], 0, 0, 0);
+    };
+    using S0 = std::integral_constant<int, 0>;
+    using S1 = std::integral_constant<int, 1>;
+    using S2 = std::integral_constant<int, 2>;
+    // one tile: reload this tile's (now free) set with tile t+3, multiply tile t out of LDS, then stage tile t+1
+    auto step = [&](auto set, auto next, int t) {
+        gload(set, t + 3);
+        compute();
+        __syncthreads();
+        if (t + 1 < nkt) lstore(next);
+        __syncthreads();
+    };
+    if (nkt > 0) {
+        gload(S0{}, 0);
+        gload(S1{}, 1);
+        gload(S2{}, 2);
+        lstore(S0{});
+    }
+    __syncthreads();
+    int t = 0;
+    for (; t + 2 < nkt; t += 3) {
+        step(S0{}, S1{}, t);
+        step(S1{}, S2{}, t + 1);
+        step(S2{}, S0{}, t + 2);
+    }
+    if (t < nkt) { step(S0{}, S1{}, t); ++t; }
+    if (t < nkt) { step(S1{}, S2{}, t); ++t; }
+
+    float* fsm = reinterpret_cast<float*>(smem);
+    if (do_csum) {
+        // the k pairs of a column are spread over lanes (c), two units and the waves w, w + 2: shuffles, then LDS
+        // (two addends per slot on top of 0 -> order-independent)
+        float* dst = p.ksplit > 1 ? p.csum_part + (int64_t)ks * p.M : p.csum;
+        if (tid < 64) fsm[tid] = 0.f;
+        __syncthreads();
+        if constexpr (!A_KC) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float v = cs[j];
+                v += __shfl_xor(v, 8);
+                v += __shfl_xor(v, 16);
+                v += __shfl_xor(v, 32);
+                if ((lane >> 3) == 0) atomicAdd(&fsm[lrA.lrow() + j], v);
+            }
+        }
+        __syncthreads();
+        if (tid < 64 && m0 + tid < p.M) dst[m0 + tid] = fsm[tid];
+        __syncthreads();
+    }
+
+    // the four partial blocks meet: wave w finishes the 32 x 32 tile (w >> 1, w & 1) and hands its other three tiles
+    // to their owners through LDS (12 slots of 4 KB = the staging area); summed in wave order 0..3 -> deterministic
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        if (t != wid) {
+            const int slot = t * 3 + (wid < t ? wid : wid - 1);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) fsm[slot * 1024 + r * 64 + lane] = acc[t >> 1][t & 1][r];
+        }
+    }
+    __syncthreads();
+    f32x16 out[1][1];
+    {
+        f32x16 own;
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+            if (t == wid) own = acc[t >> 1][t & 1];              // wid is wave-uniform: a scalar branch per candidate
+        f32x16 sum;
+        bool first = true;
+#pragma unroll
+        for (int s_ = 0; s_ < 4; ++s_) {
+            f32x16 part;
+            if (s_ == wid) part = own;
+            else {
+                const int slot = wid * 3 + (s_ < wid ? s_ : s_ - 1);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) part[r] = fsm[slot * 1024 + r * 64 + lane];
+            }
+            if (first) { sum = part; first = false; }
+            else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) sum[r] += part[r];
+            }
+        }
+        out[0][0] = sum;
+    }
+
+    const bool partial = p.ksplit > 1;
+    float* Cout = partial ? p.C + (int64_t)ks * p.split_stride : p.C;
+    const int mw = m0 + (wid >> 1) * 32, nw = n0 + (wid & 1) * 32;
+    const bool full = (mw + 32 <= p.M) && (nw + 32 <= p.N);
+    const bool ub = !partial && p.bias != nullptr;
+    const int epi = partial ? EPI_NONE : p.epi;
+    if (full) store_block_rt<1, 1, false>(out, Cout, mw, nw, l31, h, ub, epi, p);
+    else      store_block_rt<1, 1, true>(out, Cout, mw, nw, l31, h, ub, epi, p);
+}
+
+template <bool A_KC, bool B_KC>
+static int launch_x3s(const GemmParams& p, hipStream_t s) {
+    const int tiles = cdiv(p.M, 64) * cdiv(p.N, 64);
+    hipLaunchKernelGGL((gemm_x3s_kernel<A_KC, B_KC>), dim3(tiles * p.ksplit), dim3(256), 0, s, p);
+    return check_launch("gemm_x3s");
+}
+// products the small-tile split kernel takes: enough 64 x 64 tiles to matter, at least two of its k-tiles
+static bool x3s_eligible(int M, int N, int K, int ksplit) {
+    static const int min_wgs = getenv("NR_X3S_MIN_WGS") ? atoi(getenv("NR_X3S_MIN_WGS")) : 48;        // A/B switch for tools
+    return K >= 128 && (int64_t)cdiv(M, 64) * cdiv(N, 64) * ksplit >= min_wgs;
 }
 
 static std::atomic<int> g_gemm_compute{2};       // default: fp32 results from split operands on the bf16 matrix pipe
@@ -1320,6 +1661,12 @@ int choose_ksplit(int M, int N, int K) {
         const int kt = cdiv(K, BK);
         const int ks = std::min(cdiv(target, tiles), kt / 8);
         if (ks >= 2 && tiles * ks >= 200) return ks;
+        // small-tile split kernel: 64 x 64 tiles, 64-deep k-tiles; ~1.5 workgroups per CU, slices of >= 4 k-tiles
+        static const int target_s = getenv("NR_X3S_KS_WGS") ? atoi(getenv("NR_X3S_KS_WGS")) : 384;
+        const int tiles_s = cdiv(M, 64) * cdiv(N, 64);
+        const int kts = cdiv(K, XS_BK);
+        const int ks_s = std::max(1, std::min(cdiv(target_s, tiles_s), kts / 4));
+        if (x3s_eligible(M, N, K, ks_s)) return ks_s;
     }
     // dW GEMMs: tiny MxN, huge K.  Two pulls (swept on MI355X): enough workgroups to fill the
     // chip (>= 512), and slices of ~32 k-tiles — shorter slices than the fill needs only add slab traffic, longer
@@ -1361,6 +1708,7 @@ int gemm_f32(GemmParams p, bool a_kc, bool b_kc, float* workspace, size_t ws_byt
     const int x3_bm[3] = {256, 128, 64}, x3_bn[3] = {64, 128, 256};
     const bool x3 = fast && g_gemm_compute.load() == 2 && p.K >= 64 && (a_kc || !b_kc) &&
                     (int64_t)cdiv(p.M, x3_bm[x3_shape]) * cdiv(p.N, x3_bn[x3_shape]) * p.ksplit >= env_minwg;
+    const bool x3s = !x3 && fast && g_gemm_compute.load() == 2 && (a_kc || !b_kc) && x3s_eligible(p.M, p.N, p.K, p.ksplit);
     ProfScope prof(x3 ? FAM_GEMM_SPLIT : FAM_GEMM, s, 2.0 * p.M * p.N * p.K);
     if (!fast) {
         p.ksplit = 1;
@@ -1391,6 +1739,10 @@ int gemm_f32(GemmParams p, bool a_kc, bool b_kc, float* workspace, size_t ws_byt
         if (a_kc && b_kc)        rc = launch_bf16<true, true>(q, s);
         else if (a_kc && !b_kc)  rc = launch_bf16<true, false>(q, s);
         else                     rc = launch_bf16<false, false>(q, s);
+    } else if (x3s) {
+        if (a_kc && b_kc)        rc = launch_x3s<true, true>(q, s);
+        else if (a_kc && !b_kc)  rc = launch_x3s<true, false>(q, s);
+        else                     rc = launch_x3s<false, false>(q, s);
     } else if (x3) {
         const int shape = x3_shape;
         if (a_kc && b_kc)        rc = launch_x3_tile<true, true>(q, shape, s);
