@@ -914,6 +914,15 @@ struct LoaderKCX {
 #ifndef NR_X3_WGS
 #define NR_X3_WGS 2
 #endif
+#if NR_X3_EXP == 4
+// diagnostic build only (never shipped: the default build has none of this): per-workgroup cycle stamps of the x3 kernel
+__device__ unsigned long long x3_stamps[8192 * 32];
+#define X3_STAMP(i) do { if (threadIdx.x == 0 && blockIdx.x < 8192) x3_stamps[blockIdx.x * 32 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#define X3_STAMP_RT(i) do { if (threadIdx.x == 0 && blockIdx.x < 8192) x3_stamps[blockIdx.x * 32 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define X3_STAMP(i) do {} while (0)
+#define X3_STAMP_RT(i) do {} while (0)
+#endif
 __device__ __forceinline__ void split3(float x, float y, uint32_t& p0, uint32_t& p1, uint32_t& p2) {
 #if NR_X3_EXP == 1
     p0 = __builtin_amdgcn_perm(__float_as_uint(y), __float_as_uint(x), 0x07060302u);
@@ -1139,11 +1148,14 @@ __global__ __launch_bounds__(256, NR_X3_WGS) void gemm_x3_kernel(const GemmParam
     // prologue and epilogue, which only other resident workgroups can cover: a two-stage, one-workgroup-per-CU pipeline
     // measured slower on every NRMS shape (and no faster at 4096^3, where the k-loop waits on L2 either way).
     const int nkt = kt_end - kt_begin;
+    X3_STAMP(0);
+    X3_STAMP_RT(1);
     if (nkt > 0) {
         gload(kt_begin);
         lstore();
     }
     __syncthreads();
+    X3_STAMP(2);
     for (int kt = kt_begin; kt < kt_end; ++kt) {
         const bool more = kt + 1 < kt_end;
 #if NR_X3_WGS >= 3
@@ -1161,10 +1173,13 @@ __global__ __launch_bounds__(256, NR_X3_WGS) void gemm_x3_kernel(const GemmParam
         fmma(f0);
         fmma(f1);
 #endif
+        if (kt - kt_begin < 12) X3_STAMP(3 + 2 * (kt - kt_begin));
         __syncthreads();                                  // everyone is done reading the single stage
         if (more) lstore();
         __syncthreads();
+        if (kt - kt_begin < 12) X3_STAMP(4 + 2 * (kt - kt_begin));
     }
+    X3_STAMP(28);
     if (do_csum) {
         // lanes that share 4 columns (same a, all c) meet by shuffles, the units of one column group (two k halves, on
         // one or two waves) through LDS: two addends per slot on top of 0 -> order-independent
@@ -1201,7 +1216,16 @@ __global__ __launch_bounds__(256, NR_X3_WGS) void gemm_x3_kernel(const GemmParam
 #endif
     if (full) store_block_rt<2, 2, false>(acc, Cout, mw, nw, l31, h, ub, epi, p);
     else      store_block_rt<2, 2, true>(acc, Cout, mw, nw, l31, h, ub, epi, p);
+    X3_STAMP(29);
+    X3_STAMP_RT(30);
 }
+#if NR_X3_EXP == 4
+}  // namespace nr
+extern "C" int nr_debug_x3_stamps(unsigned long long* host, int n) {
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(nr::x3_stamps), sizeof(unsigned long long) * n);
+}
+namespace nr {
+#endif
 
 template <bool A_KC, bool B_KC, int WR, int WC>
 static int launch_x3(const GemmParams& p, hipStream_t s) {
