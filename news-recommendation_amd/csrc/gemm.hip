@@ -951,6 +951,9 @@ __device__ __forceinline__ void store_kc_x3(uint32_t* lds, const f32x4 (&r)[ROWS
         *reinterpret_cast<uint2*>(d) = v0;
         *reinterpret_cast<uint2*>(d + PL) = v1;
         *reinterpret_cast<uint2*>(d + 2 * PL) = v2;
+        // keep each pass's stores behind its own split: left alone the compiler sinks all stores to the end of the phase,
+        // where the four waves then queue on the LDS write path (~85 B/clk) after having left it idle during the split
+        __builtin_amdgcn_sched_barrier(0);
     }
 }
 
@@ -1173,11 +1176,13 @@ __global__ __launch_bounds__(256, NR_X3_WGS) void gemm_x3_kernel(const GemmParam
         fmma(f0);
         fmma(f1);
 #endif
-        if (kt - kt_begin < 12) X3_STAMP(3 + 2 * (kt - kt_begin));
+        if (kt - kt_begin < 6) X3_STAMP(3 + 4 * (kt - kt_begin));
         __syncthreads();                                  // everyone is done reading the single stage
+        if (kt - kt_begin < 6) X3_STAMP(4 + 4 * (kt - kt_begin));
         if (more) lstore();
+        if (kt - kt_begin < 6) X3_STAMP(5 + 4 * (kt - kt_begin));
         __syncthreads();
-        if (kt - kt_begin < 12) X3_STAMP(4 + 2 * (kt - kt_begin));
+        if (kt - kt_begin < 6) X3_STAMP(6 + 4 * (kt - kt_begin));
     }
     X3_STAMP(28);
     if (do_csum) {

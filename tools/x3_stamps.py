@@ -20,8 +20,15 @@ st = st[:nwg]
 nkt = (K + 31) // 32
 t0 = st[:, 0]
 pro = st[:, 2] - t0
-comp = np.stack([st[:, 3 + 2 * i] - (st[:, 2] if i == 0 else st[:, 2 + 2 * i]) for i in range(min(nkt, 12))], 1)
-stage = np.stack([st[:, 4 + 2 * i] - st[:, 3 + 2 * i] for i in range(min(nkt, 12))], 1)
+nk = min(nkt, 6)
+comp = np.stack([st[:, 3 + 4 * i] - (st[:, 2] if i == 0 else st[:, 2 + 4 * i]) for i in range(nk)], 1)
+bar1 = np.stack([st[:, 4 + 4 * i] - st[:, 3 + 4 * i] for i in range(nk)], 1)
+stor = np.stack([st[:, 5 + 4 * i] - st[:, 4 + 4 * i] for i in range(nk)], 1)
+bar2 = np.stack([st[:, 6 + 4 * i] - st[:, 5 + 4 * i] for i in range(nk)], 1)
+stage = bar1 + stor + bar2
+print("  barrier 1 (wave 0 waits for the others)", [int(v) for v in np.median(bar1, 0)])
+print("  wait for loads + split + LDS stores", [int(v) for v in np.median(stor, 0)])
+print("  barrier 2", [int(v) for v in np.median(bar2, 0)])
 loop_end = st[:, 28] - t0
 end = st[:, 29] - t0
 rt = (st[:, 30] - st[:, 1])           # 100 MHz ticks
