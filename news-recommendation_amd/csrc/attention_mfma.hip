@@ -19,6 +19,7 @@
 // Dropout keep bits are drawn once, in the T orientation (4 consecutive keys share one Philox call
 // when S % 4 == 0), and handed to the N orientation as a 32-bit word per query through LDS.
 #include "common.h"
+#include <cstdlib>
 #include "seqops.h"
 
 namespace nr {
@@ -445,8 +446,10 @@ static int launch_fwd(const T* qkv, const int64_t* mask, T* ctx, float* row_max,
     const int dhp = dh <= 32 ? 32 : 64;
     const int hpg = dhp == 32 ? 4 : 2;
     const dim3 grid((unsigned)(N * ((H + hpg - 1) / hpg)));
-    const size_t lds = (size_t)3 * hpg * 32 * (dhp + 1) * sizeof(float);
+    static const size_t lds_pad = getenv("NR_ATTN_LDS_PAD") ? (size_t)atoi(getenv("NR_ATTN_LDS_PAD")) : 0;      // occupancy experiment
+    const size_t lds = (size_t)3 * hpg * 32 * (dhp + 1) * sizeof(float) + lds_pad;
     if (dhp == 32) {
+        if (lds_pad) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mhsa_fwd_mfma_kernel<32, T, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         hipLaunchKernelGGL((mhsa_fwd_mfma_kernel<32, T, 4>), grid, dim3(256), lds, s, qkv, mask, ctx, row_max, row_sum, S, H, dh, dc, vec);
     } else {
         static bool once = false;

@@ -1627,6 +1627,34 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmParams p, 
     }
 }
 
+// the plain case (dW: no bias, no epilogue, 16-byte rows): four outputs per thread, four slabs in flight.  The scalar
+// kernel above walks its slabs one dependent load at a time: 47 slabs of dW[300,300] took 24.6 us for 17 MB.
+__global__ __launch_bounds__(256) void splitk_reduce4_kernel(const GemmParams p, const float* __restrict__ slabs) {
+    const int n4 = p.N >> 2;
+    const int64_t total = (int64_t)p.M * n4;
+    if (p.csum) {
+        for (int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; m < p.M; m += (int64_t)gridDim.x * blockDim.x) {
+            float v = 0.f;
+            for (int s = 0; s < p.ksplit; ++s) v += p.csum_part[(int64_t)s * p.M + m];
+            p.csum[m] = v;
+        }
+    }
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+        const int m = (int)(idx / n4), n = (int)(idx - (int64_t)m * n4) << 2;
+        const float* src = slabs + (int64_t)m * p.N + n;
+        f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = a0, a2 = a0, a3 = a0;
+        int s = 0;
+        for (; s + 4 <= p.ksplit; s += 4) {                // fixed order: the result does not depend on the launch
+            a0 += ldg4(src + (int64_t)s * p.split_stride);
+            a1 += ldg4(src + (int64_t)(s + 1) * p.split_stride);
+            a2 += ldg4(src + (int64_t)(s + 2) * p.split_stride);
+            a3 += ldg4(src + (int64_t)(s + 3) * p.split_stride);
+        }
+        for (; s < p.ksplit; ++s) a0 += ldg4(src + (int64_t)s * p.split_stride);
+        *reinterpret_cast<f32x4*>(p.C + (int64_t)m * p.ldc + n) = (a0 + a1) + (a2 + a3);
+    }
+}
+
 // slow but fully general fallback (any K/N alignment): one thread per output element
 template <bool A_KC, bool B_KC>
 __global__ __launch_bounds__(256) void gemm_naive_kernel(const GemmParams p) {
@@ -1800,6 +1828,12 @@ int gemm_f32(GemmParams p, bool a_kc, bool b_kc, float* workspace, size_t ws_byt
         GemmParams r = p;
         r.split_stride = (int64_t)p.M * p.N;
         const int64_t total = (int64_t)p.M * p.N;
+        if (p.epi == EPI_NONE && !p.bias && (p.N & 3) == 0 && (p.ldc & 3) == 0 && (reinterpret_cast<uintptr_t>(p.C) & 15) == 0 &&
+            (reinterpret_cast<uintptr_t>(slabs) & 15) == 0) {
+            const int grid = (int)std::min<int64_t>((total / 4 + 255) / 256, 4096);
+            hipLaunchKernelGGL(splitk_reduce4_kernel, dim3(grid), dim3(256), 0, s, r, slabs);
+            return check_launch("splitk_reduce4");
+        }
         const int grid = (int)std::min<int64_t>((total + 255) / 256, 4096);
         hipLaunchKernelGGL(splitk_reduce_kernel, dim3(grid), dim3(256), 0, s, r, slabs);
         return check_launch("splitk_reduce");

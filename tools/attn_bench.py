@@ -1,0 +1,27 @@
+"""time the attention kernels at the news-tower shape: python tools/attn_bench.py [N S H dh]"""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "news-recommendation_amd"))
+import torch
+from newsrec_hip import ops
+N, S, H, dh = (int(v) for v in sys.argv[1:5]) if len(sys.argv) > 4 else (1760, 32, 12, 25)
+D = H * dh
+qkv = torch.randn(N * S, 3 * D, device="cuda")
+mask = torch.ones(N, S, dtype=torch.int64, device="cuda")
+def timeit(fn, n=20):
+    for _ in range(3): fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(n): fn()
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / n * 1e3
+q = qkv.clone().requires_grad_(True)
+out = ops.mhsa(q, mask, N, S, H, dh)
+print("fwd us", round(timeit(lambda: ops.mhsa(qkv, mask, N, S, H, dh)), 1))
+g = torch.randn_like(out)
+def fb():
+    q.grad = None
+    o = ops.mhsa(q, mask, N, S, H, dh)
+    o.backward(g)
+print("fwd+bwd us", round(timeit(fb), 1))
