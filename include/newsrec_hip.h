@@ -66,7 +66,13 @@ int nr_get_gemm_compute(void);
 /* ---- (i) token-embedding gather — nn.Embedding lookup, models/modules/encoder.py:52,135 ------
  * out[r,:] = table[ids[r],:] (bit-exact).  *oob_flag (device int, may be NULL) is set to 1 if any
  * id is outside [0,V) (such rows read row 0 instead of faulting).
- * Also used for news_embeddings[his_idx] / [cdd_idx], models/BaseModel.py:214-215. */
+ * Also used for news_embeddings[his_idx] / [cdd_idx], models/BaseModel.py:214-215.
+ * With oob_flag == NULL the library's own per-GPU index flag is raised instead; the *_from_table forms of
+ * nr_query_pool_fwd_f32 / nr_score_fwd_f32 / nr_seq_reduce_f32 (idx != NULL) raise it too when they clamp an index.
+ * nr_index_status copies that flag to *out_flag (0 / 1), clears it and synchronises the stream: call it where the
+ * caller syncs anyway.  The reference's nn.Embedding / tensor indexing raise IndexError at this point
+ * (encoder.py:52,135; BaseModel.py:214-215). */
+int nr_index_status(int* out_flag, void* stream);
 int nr_gather_rows_f32(const float* table, int64_t V, int64_t E, const int64_t* ids, int64_t n, float* out, int* oob_flag, void* stream);
 /* embedding backward (autograd of encoder.py:52): grad_table[ids[r],:] += grad_rows[r,:], rows with
  * ids[r] == padding_idx skipped (BERT word_embeddings has padding_idx = 0).  grad_table is NOT zeroed. */

@@ -176,6 +176,8 @@ int nr_prof_read(int family, double* ms, int64_t* launches, double* work) {
     return NR_OK;
 }
 
+int nr_index_status(int* out_flag, void* stream) { return index_status(out_flag, S(stream)); }
+
 int nr_gather_rows_f32(const float* table, int64_t V, int64_t E, const int64_t* ids, int64_t n, float* out, int* oob_flag, void* stream) {
     NR_CHECK_ARG(n >= 0 && V > 0 && E > 0, "gather_rows: bad sizes n=%lld V=%lld E=%lld", (long long)n, (long long)V, (long long)E);
     NR_CHECK_ARG(n == 0 || (table && ids && out), "gather_rows: null pointer");

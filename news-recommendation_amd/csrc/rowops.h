@@ -20,6 +20,11 @@ struct DropoutCfg {
     const int* offs = nullptr;      // attention kernels: sequence n owns packed rows offs[n] .. offs[n+1]; NULL = dense [N,S]
 };
 
+// the library's index flag (one int per GPU, in a file-scope __device__ variable): raised by every kernel that clamps a
+// row index into its table instead of faulting (gather with no caller flag, the *_from_table forms of pooling / scoring /
+// sequence sums); read and cleared by nr_index_status.  nullptr if its address cannot be resolved (kernels then only clamp).
+int* index_flag_ptr();
+int index_status(int* host_out, hipStream_t s);
 int gather_rows(const float* table, int64_t V, int E, const int64_t* ids, int64_t n, float* out, int* oob_flag, hipStream_t s);
 int scatter_add_rows(const float* grad_rows, const int64_t* ids, int64_t n, int E, int64_t V, int64_t padding_idx,
                      float* grad_table, hipStream_t s);

@@ -4,6 +4,7 @@
 // i.e. every wave instruction touches 1 KiB of one row (coalesced).
 #include "common.h"
 #include "rowops.h"
+#include <mutex>
 
 namespace nr {
 
@@ -12,6 +13,37 @@ constexpr int WAVES_PER_BLOCK = 4;
 static inline bool aligned16(const void* a, const void* b = nullptr, const void* c = nullptr, const void* d = nullptr) {
     return ((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b) | reinterpret_cast<uintptr_t>(c) |
              reinterpret_cast<uintptr_t>(d)) & 15) == 0;
+}
+
+// ------------------------------------------------------------------ index flag
+static __device__ int g_index_flag;
+int* index_flag_ptr() {
+    static std::mutex mu;
+    static int* per_dev[64];
+    static bool tried[64];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+    std::lock_guard<std::mutex> lk(mu);
+    if (!tried[dev]) {
+        tried[dev] = true;
+        int* ptr = nullptr;
+        if (hipGetSymbolAddress(reinterpret_cast<void**>(&ptr), HIP_SYMBOL(g_index_flag)) == hipSuccess && ptr &&
+            hipMemset(ptr, 0, sizeof(int)) == hipSuccess)
+            per_dev[dev] = ptr;
+    }
+    return per_dev[dev];
+}
+int index_status(int* host_out, hipStream_t s) {
+    NR_CHECK_ARG(host_out, "nr_index_status: null output");
+    *host_out = 0;
+    int* flag = index_flag_ptr();
+    if (!flag) return NR_OK;
+    if (hipMemcpyAsync(host_out, flag, sizeof(int), hipMemcpyDeviceToHost, s) != hipSuccess || hipMemsetAsync(flag, 0, sizeof(int), s) != hipSuccess ||
+        hipStreamSynchronize(s) != hipSuccess) {
+        set_error("nr_index_status: reading the flag failed");
+        return NR_ERR_LAUNCH;
+    }
+    return NR_OK;
 }
 
 // ------------------------------------------------------------------ gather
@@ -31,7 +63,7 @@ __global__ __launch_bounds__(256) void gather_rows_kernel(const float* __restric
             const int64_t r = r0 + k;
             int64_t v = (r < n) ? ids[r] : 0;
             if (v < 0 || v >= V) {            // never fault on a bad index: flag it, read row 0
-                if (lane == 0) *oob_flag = 1;
+                if (lane == 0 && oob_flag) *oob_flag = 1;
                 v = 0;
             }
             id[k] = v;
@@ -60,6 +92,7 @@ __global__ __launch_bounds__(256) void gather_rows_kernel(const float* __restric
 int gather_rows(const float* table, int64_t V, int E, const int64_t* ids, int64_t n, float* out, int* oob_flag,
                 hipStream_t s) {
     if (n == 0) return NR_OK;
+    if (!oob_flag) oob_flag = index_flag_ptr();            // no caller flag: the library's own (nr_index_status)
     ProfScope prof(FAM_GATHER, s, 2.0 * n * E * 4 + 8.0 * n);
     const bool vec = (E % 4 == 0) && ((reinterpret_cast<uintptr_t>(table) | reinterpret_cast<uintptr_t>(out)) % 16 == 0);
     const int grid = (int)std::min<int64_t>(cdiv(n, WAVES_PER_BLOCK * 4), 8192);

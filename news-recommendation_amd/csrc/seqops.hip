@@ -8,6 +8,7 @@
 // per-position scalars (scores, probabilities, logits) live one per lane (C <= 64; pooling: SL = 1 or 2 per lane, S <= 128).
 #include "common.h"
 #include "seqops.h"
+#include "rowops.h"
 
 namespace nr {
 
@@ -15,12 +16,15 @@ constexpr float MASK_FILL = -1e5f;
 constexpr int WPB = 4;                 // waves (sequences) per 256-thread block
 
 // row pointer of position s in sequence n: either dense [nseq,S,D] or gathered from a table
-// (a bad index is clamped into the table instead of faulting the GPU)
+// (a bad index is clamped into the table instead of faulting the GPU, and raises the library's index flag: nr_index_status)
 __device__ __forceinline__ const float* row_ptr(const float* dense, const float* table, const int64_t* idx, int64_t nrows,
-                                                int64_t n, int S, int s, int D) {
+                                                int64_t n, int S, int s, int D, int* oob) {
     if (idx) {
         int64_t r = idx[n * S + s];
-        r = r < 0 ? 0 : (r >= nrows ? nrows - 1 : r);
+        if (r < 0 || r >= nrows) {
+            if (oob) *oob = 1;
+            r = r < 0 ? 0 : nrows - 1;
+        }
         return table + r * (int64_t)D;
     }
     return dense + (n * S + s) * (int64_t)D;
@@ -75,7 +79,7 @@ __global__ __launch_bounds__(256) void pool_fwd_kernel(const float* __restrict__
                                                        int64_t nrows,
                                                        const float* __restrict__ query, const int64_t* __restrict__ mask,
                                                        float* __restrict__ out, float* __restrict__ prob, int64_t nseq,
-                                                       int S, int D, const int* __restrict__ offs) {
+                                                       int S, int D, const int* __restrict__ offs, int* __restrict__ oob) {
     __shared__ float sc[64 * SL];
     __shared__ __attribute__((aligned(16))) float part[WPB][IT * 256];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -98,7 +102,7 @@ __global__ __launch_bounds__(256) void pool_fwd_kernel(const float* __restrict__
 #pragma unroll
         for (int b = 0; b < PB; ++b) {
             const int s = s0 + b * WPB;
-            if (s < Sn) load_row<IT>(k[b], row_ptr(key, table, idx, nrows, n, S, s, D), D, lane);
+            if (s < Sn) load_row<IT>(k[b], row_ptr(key, table, idx, nrows, n, S, s, D, oob), D, lane);
         }
 #pragma unroll
         for (int b = 0; b < PB; ++b) {
@@ -129,7 +133,7 @@ __global__ __launch_bounds__(256) void pool_fwd_kernel(const float* __restrict__
 #pragma unroll
         for (int b = 0; b < PB; ++b) {
             const int s = s0 + b * WPB;
-            if (s < Sn) load_row<IT>(v[b], row_ptr(value, table, idx, nrows, n, S, s, D), D, lane);
+            if (s < Sn) load_row<IT>(v[b], row_ptr(value, table, idx, nrows, n, S, s, D, oob), D, lane);
         }
 #pragma unroll
         for (int b = 0; b < PB; ++b) {
@@ -258,7 +262,7 @@ __global__ __launch_bounds__(256) void score_fwd_kernel(const float* __restrict_
                                                         const int64_t* __restrict__ idx, int64_t nrows,
                                                         const float* __restrict__ user,
                                                         const int64_t* __restrict__ label, float* __restrict__ logits,
-                                                        float* __restrict__ loss_b, int64_t B, int C, int D) {
+                                                        float* __restrict__ loss_b, int64_t B, int C, int D, int* __restrict__ oob) {
     const int lane = threadIdx.x & 63;
     const int64_t b = (int64_t)blockIdx.x * WPB + (threadIdx.x >> 6);
     if (b >= B) return;
@@ -268,7 +272,7 @@ __global__ __launch_bounds__(256) void score_fwd_kernel(const float* __restrict_
     float mylogit = -INFINITY;
     for (int c = 0; c < C; ++c) {
         float4 v[IT];
-        load_row<IT>(v, row_ptr(cdd, table, idx, nrows, b, C, c, D), D, lane);
+        load_row<IT>(v, row_ptr(cdd, table, idx, nrows, b, C, c, D, oob), D, lane);
         const float x = dot_rows<IT>(v, u) / sq;
         if (lane == (c & 63)) mylogit = x;
         if ((c & 63) == 63 || c == C - 1) {                  // flush 64 logits at a time: any C (the loss path needs C <= 64)
@@ -329,7 +333,7 @@ __global__ __launch_bounds__(256) void score_bwd_kernel(const float* __restrict_
 template <int IT>
 __global__ __launch_bounds__(256) void seq_reduce_kernel(const float* __restrict__ x, const float* __restrict__ table,
                                                          const int64_t* __restrict__ idx, int64_t nrows,
-                                                         float* __restrict__ out, int64_t nseq, int S, int D, int mean) {
+                                                         float* __restrict__ out, int64_t nseq, int S, int D, int mean, int* __restrict__ oob) {
     const int lane = threadIdx.x & 63;
     const int64_t n = (int64_t)blockIdx.x * WPB + (threadIdx.x >> 6);
     if (n >= nseq) return;
@@ -338,7 +342,7 @@ __global__ __launch_bounds__(256) void seq_reduce_kernel(const float* __restrict
     for (int it = 0; it < IT; ++it) acc[it] = make_float4(0.f, 0.f, 0.f, 0.f);
     for (int s = 0; s < S; ++s) {
         float4 v[IT];
-        load_row<IT>(v, row_ptr(x, table, idx, nrows, n, S, s, D), D, lane);
+        load_row<IT>(v, row_ptr(x, table, idx, nrows, n, S, s, D, oob), D, lane);
 #pragma unroll
         for (int it = 0; it < IT; ++it) { acc[it].x += v[it].x; acc[it].y += v[it].y; acc[it].z += v[it].z; acc[it].w += v[it].w; }
     }
@@ -400,7 +404,7 @@ int pool_fwd(const float* key, const float* value, const float* table, const int
     NR_UNSUPPORTED(offs && idx, "pooling: packed sequences and table gather are exclusive");
     ProfScope prof(FAM_POOL, s, (double)(offs ? rows : nseq * S) * (2.0 * D * 4) + (double)nseq * D * 4);
     const dim3 grid((unsigned)nseq);
-    NR_POOL_DISPATCH(pool_fwd_kernel, grid, key, value, table, idx, nrows, query, mask, out, prob, nseq, S, D, offs);
+    NR_POOL_DISPATCH(pool_fwd_kernel, grid, key, value, table, idx, nrows, query, mask, out, prob, nseq, S, D, offs, idx ? index_flag_ptr() : nullptr);
     return check_launch("pool_fwd");
 }
 
@@ -421,7 +425,7 @@ int score_fwd(const float* cdd, const float* table, const int64_t* idx, int64_t 
     if (int rc = check_seq_dims("scoring", C, D, loss_b ? 64 : 65536)) return rc;       // plain logits: any C; fused CE: one logit per lane
     ProfScope prof(FAM_SCORE, s, (double)B * ((C + 1.0) * D * 4 + C * 4 + (idx ? C * 8 : 0)));
     const dim3 grid(cdiv(B, WPB));
-    NR_SEQ_DISPATCH(score_fwd_kernel, grid, cdd, table, idx, nrows, user, label, logits, loss_b, B, C, D);
+    NR_SEQ_DISPATCH(score_fwd_kernel, grid, cdd, table, idx, nrows, user, label, logits, loss_b, B, C, D, idx ? index_flag_ptr() : nullptr);
     return check_launch("score_fwd");
 }
 
@@ -441,7 +445,7 @@ int seq_reduce(const float* x, const float* table, const int64_t* idx, int64_t n
     NR_UNSUPPORTED(D % 4 != 0 || D > 2048 || D < 4, "seq_reduce: D=%d must be a multiple of 4 in [4,2048]", D);
     ProfScope prof(FAM_POOL, s, (double)nseq * (S + 1.0) * D * 4);
     const dim3 grid(cdiv(nseq, WPB));
-    NR_SEQ_DISPATCH(seq_reduce_kernel, grid, x, table, idx, nrows, out, nseq, S, D, mean);
+    NR_SEQ_DISPATCH(seq_reduce_kernel, grid, x, table, idx, nrows, out, nseq, S, D, mean, idx ? index_flag_ptr() : nullptr);
     return check_launch("seq_reduce");
 }
 

@@ -257,6 +257,11 @@ class TwoTowerBaseModel(BaseModel):
             user = self._encode_user(his_news_embedding=his, his_mask=his_mask.to(self.device))
         return user
 
+    def _check_indices(self, where):
+        """a token id / news index outside its table raises here (the kernels clamp and flag it; ops.check_indices)"""
+        if torch.device(self.device).type == "cuda":
+            ops.check_indices(where)
+
     @torch.no_grad()
     def encode_news(self, manager, loader_news):
         """build the [Nn, D] news-vector cache.  Rows are independent, so each rank encodes the
@@ -281,6 +286,7 @@ class TwoTowerBaseModel(BaseModel):
             else:
                 x = {"cdd_token_id": torch.from_numpy(ds.token_ids[s:e]), "cdd_attn_mask": torch.from_numpy(ds.attn_masks[s:e])}
             local[s - lo:e - lo] = self._corpus_vectors(x)
+        self._check_indices("encode_news")
         if manager.distributed:
             cap = max(round(per * (r + 1)) - round(per * r) for r in range(ws))
             pad = torch.zeros((cap, self.hidden_dim), dtype=torch.float32, device=self.device)
@@ -301,6 +307,7 @@ class TwoTowerBaseModel(BaseModel):
             masks.append(x["cdd_mask"])
             if with_labels:
                 labels.append(x["label"])
+        self._check_indices("infer")
         dev = self.device
         Ce = manager.impr_size
         cat = lambda ts, shape, dt: (torch.cat([t.reshape(shape) for t in ts]).to(dev) if ts else torch.zeros(shape, dtype=dt)[:0].to(dev))

@@ -46,6 +46,7 @@ _SIGS = {
     "nr_version": (c_int, []),
     "nr_last_error": (C.c_char_p, []),
     "nr_prof_enable": (c_int, [c_int]),
+    "nr_index_status": (c_int, [C.POINTER(c_int), c_fp]),
     "nr_set_gemm_compute": (c_int, [c_int]),
     "nr_get_gemm_compute": (c_int, []),
     "nr_prof_read": (c_int, [c_int, C.POINTER(C.c_double), C.POINTER(c_i64), C.POINTER(C.c_double)]),

@@ -83,6 +83,19 @@ def gather_rows(table, ids):
     return out
 
 
+def check_indices(where=""):
+    """raise NewsrecError if any row gather since the last call met an index outside its table (a token id beyond the
+    vocabulary, a news index beyond the cache: wrong vocab.txt, a stale cache of another split).  The kernels clamp such
+    an index instead of faulting and raise a per-GPU flag; this reads and clears it (one 4-byte copy + a stream sync), so
+    call it where the host syncs anyway.  The reference's nn.Embedding / tensor indexing raise IndexError there."""
+    import ctypes
+    flag = ctypes.c_int(0)
+    check(lib().nr_index_status(ctypes.byref(flag), _stream()), "nr_index_status")
+    if flag.value:
+        raise NewsrecError(f"index out of range in a row gather{' (' + where + ')' if where else ''}: a token id or news index lies outside "
+                           "its table (the kernels read a clamped row instead of faulting; results since the last check are invalid)")
+
+
 def gather_rows_i64(table, idx):
     """rows of an int64 [Nn,T] table (news token ids / masks resident in HBM) by news index [...] -> [...,T].
     The copy kernel moves 32-bit words, so the int64 table is viewed as [Nn, 2T] words: bit-exact."""

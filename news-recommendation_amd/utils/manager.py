@@ -294,6 +294,8 @@ class Manager():
                 d = loss.detach()
                 epoch_loss = d if epoch_loss is None else epoch_loss + d        # stays on the device
                 if step % 5 == 0:
+                    if hasattr(core, "_check_indices"):
+                        core._check_indices("train step")         # the float() below syncs anyway
                     bar.set_description("epoch: {:d}, step: {:d}, loss: {:.4f}".format(epoch + 1, step, float(epoch_loss) / step))
                 if total_steps > hold_step and total_steps % validate_step == 0:
                     result = core.dev(self, loaders)

@@ -624,3 +624,28 @@ def test_device_metrics_vs_host(n_impr, Ce, max_cand, ties):
         if impr[0] != impr[-1] and (impr == impr[0]).sum() > 1:
             assert device_compute_metrics(torch.from_numpy(impr[perm]).cuda(), torch.from_numpy(masks[perm]).cuda(),
                                           torch.from_numpy(preds[perm]).cuda(), torch.from_numpy(labels[perm]).cuda(), names) is None
+
+
+def test_out_of_range_index_is_reported(ops):
+    """a row index outside its table never faults the GPU (the kernels clamp it) and never passes silently either: the
+    library's index flag is raised and ops.check_indices() turns it into an error at the caller's next sync point — the
+    reference's nn.Embedding / tensor indexing raise IndexError there (encoder.py:52, BaseModel.py:214-215)."""
+    from newsrec_hip._lib import NewsrecError
+    g = G(77)
+    table = torch.randn(100, 8, generator=g).cuda()
+    user = torch.randn(2, 1, 8, generator=g).cuda()
+    query = torch.randn(1, 8, generator=g).cuda()
+    ops.check_indices()                                       # start clean
+    good = torch.tensor([[0, 3], [7, 99]]).cuda()
+    ops.gather_rows(table, good); ops.score_from_table(table, good, user); ops.pool_from_table(table, good, query)
+    ops.seq_reduce_from_table(table, good)
+    ops.check_indices("in range")                              # nothing to report
+    for bad in (torch.tensor([[0, 3], [7, 100]]), torch.tensor([[0, -1], [7, 5]])):
+        bad = bad.cuda()
+        for name, fn in (("gather", lambda: ops.gather_rows(table, bad)), ("score", lambda: ops.score_from_table(table, bad, user)),
+                         ("pool", lambda: ops.pool_from_table(table, bad, query)), ("sum", lambda: ops.seq_reduce_from_table(table, bad))):
+            out = fn()
+            assert torch.isfinite(out).all(), name
+            with pytest.raises(NewsrecError, match="out of range"):
+                ops.check_indices(name)
+            ops.check_indices(name)                            # reading the flag cleared it
