@@ -1274,9 +1274,11 @@ constexpr int XS_BK = 64;
 constexpr int XS_LDW = 32;                                   // dwords per LDS row
 __device__ __forceinline__ int xs_swz(int row) { return (row >> 1) & 7; }
 
-struct LoaderKCS {                      // 64 rows x 64 k floats: thread loads f32x4 (row = t/16 + 16*i, k = (t%16)*4)
+constexpr int XS_NT = 512;                                   // threads per workgroup: 8 waves
+constexpr int XS_NW = XS_NT / 64;
+struct LoaderKCS {                      // 64 rows x 64 k floats: thread loads f32x4 (row = t/16 + 32*i, k = (t%16)*4), i = 0, 1
     const float* base;
-    uint32_t off[4];
+    uint32_t off[2];
     unsigned valid, first, last;
     int c4;
     const float* safe;
@@ -1286,8 +1288,8 @@ struct LoaderKCS {                      // 64 rows x 64 k floats: thread loads f
         base = base_ + (int64_t)row0 * ld;
         valid = first = last = 0;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int r = row0 + (tid >> 4) + 16 * i;
+        for (int i = 0; i < 2; ++i) {
+            const int r = row0 + (tid >> 4) + 32 * i;
             const bool ok = r < nrows;
             off[i] = (uint32_t)((ok ? r - row0 : 0) * (int)ld + c4) * 4u;
             if (ok) valid |= 1u << i;
@@ -1298,12 +1300,7 @@ struct LoaderKCS {                      // 64 rows x 64 k floats: thread loads f
             }
         }
     }
-    __device__ __forceinline__ void load_full(f32x4 (&r)[4], int k0) const {
-        const char* kb = reinterpret_cast<const char*>(base + k0);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) r[i] = ldg4(kb + off[i]);
-    }
-    __device__ __forceinline__ void load(f32x4 (&r)[4], int k0, int K, int convE) const {
+    __device__ __forceinline__ void load(f32x4 (&r)[2], int k0, int K, int convE) const {
         const int k = k0 + c4;
         const bool kok = k < K;
         const unsigned dead = (k < convE ? first : 0u) | ((convE > 0 && k >= 2 * convE) ? last : 0u);
@@ -1312,19 +1309,19 @@ struct LoaderKCS {                      // 64 rows x 64 k floats: thread loads f
         const char* kb = reinterpret_cast<const char*>(base + k0);
         const char* sf = reinterpret_cast<const char*>(safe);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < 2; ++i) {
             const bool o = (live >> i) & 1u;
             const f32x4 v = ldg4(o ? kb + off[i] : sf);
             r[i] = o ? v : z;
         }
     }
 };
-__device__ __forceinline__ void store_kc_xs(uint32_t* lds, const f32x4 (&r)[4], int tid) {
+__device__ __forceinline__ void store_kc_xs(uint32_t* lds, const f32x4 (&r)[2], int tid) {
     constexpr int PL = 64 * XS_LDW;
     const int chunk = (tid & 15) >> 1, half = (tid & 1) * 2, row0 = tid >> 4;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int row = row0 + 16 * i;
+    for (int i = 0; i < 2; ++i) {
+        const int row = row0 + 32 * i;
         uint2 v0, v1, v2;
         split3(r[i][0], r[i][1], v0.x, v1.x, v2.x);
         split3(r[i][2], r[i][3], v0.y, v1.y, v2.y);
@@ -1334,7 +1331,7 @@ __device__ __forceinline__ void store_kc_xs(uint32_t* lds, const f32x4 (&r)[4], 
         *reinterpret_cast<uint2*>(d + 2 * PL) = v2;
     }
 }
-// reduction-major 64 (k) x 64 columns: lane = 8*c + a -> columns 32*(w&1) + 4*a .. +3, k pairs 8*((w>>1) + 2*i) + c, i = 0, 1
+// reduction-major 64 (k) x 64 columns: lane = 8*c + a of wave w -> columns 32*(w&1) + 4*a .. +3, k pair 8*(w>>1) + c
 struct LoaderRMS {
     const float* base;
     int64_t ld;
@@ -1348,62 +1345,48 @@ struct LoaderRMS {
         c = lane >> 3;
     }
     __device__ __forceinline__ int lrow() const { return 32 * (w & 1) + 4 * a; }
-    __device__ __forceinline__ int kp(int i) const { return 8 * ((w >> 1) + 2 * i) + c; }
+    __device__ __forceinline__ int kp() const { return 8 * (w >> 1) + c; }
     __device__ __forceinline__ bool conv_dead(int k, int col, int convT, int convE) const {
         if (convT <= 0) return false;
         const int t = k % convT;
         return (t == 0 && col < convE) || (t == convT - 1 && col >= 2 * convE);
     }
-    __device__ __forceinline__ void load_full(f32x4 (&r)[4], int k0) const {
-        const uint32_t rowb = (uint32_t)ld * 4u;
-        const int col = col0 + lrow();
-        const uint32_t off = (uint32_t)(2 * c * (int)ld + (col < ncols ? col : col0)) * 4u;
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const char* kb = reinterpret_cast<const char*>(base + (int64_t)(k0 + 16 * ((w >> 1) + 2 * i)) * ld);     // uniform
-            r[2 * i] = ldg4(kb + off);
-            r[2 * i + 1] = ldg4(kb + off + rowb);
-        }
-    }
-    __device__ __forceinline__ void load(f32x4 (&r)[4], int k0, int K, int convT, int convE) const {
+    __device__ __forceinline__ void load(f32x4 (&r)[2], int k0, int K, int convT, int convE) const {
         const uint32_t rowb = (uint32_t)ld * 4u;
         const f32x4 z = {0.f, 0.f, 0.f, 0.f};
         const char* sf = reinterpret_cast<const char*>(safe);
         const int col = col0 + lrow();
         const bool cvalid = col < ncols;
         const uint32_t off = (uint32_t)(2 * c * (int)ld + (cvalid ? col : col0)) * 4u;
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const char* kb = reinterpret_cast<const char*>(base + (int64_t)(k0 + 16 * ((w >> 1) + 2 * i)) * ld);
-            const int k = k0 + 2 * kp(i);
-            const bool o0 = cvalid && k < K && !conv_dead(k, col, convT, convE), o1 = cvalid && k + 1 < K && !conv_dead(k + 1, col, convT, convE);
-            const f32x4 v0 = ldg4(o0 ? kb + off : sf), v1 = ldg4(o1 ? kb + off + rowb : sf);
-            r[2 * i] = o0 ? v0 : z;
-            r[2 * i + 1] = o1 ? v1 : z;
-        }
+        const char* kb = reinterpret_cast<const char*>(base + (int64_t)(k0 + 16 * (w >> 1)) * ld);      // uniform
+        const int k = k0 + 2 * kp();
+        const bool o0 = cvalid && k < K && !conv_dead(k, col, convT, convE), o1 = cvalid && k + 1 < K && !conv_dead(k + 1, col, convT, convE);
+        const f32x4 v0 = ldg4(o0 ? kb + off : sf), v1 = ldg4(o1 ? kb + off + rowb : sf);
+        r[0] = o0 ? v0 : z;
+        r[1] = o1 ? v1 : z;
     }
 };
-__device__ __forceinline__ void store_rm_xs(uint32_t* lds, const f32x4 (&r)[4], const LoaderRMS& L) {
+__device__ __forceinline__ void store_rm_xs(uint32_t* lds, const f32x4 (&r)[2], const LoaderRMS& L) {
     constexpr int PL = 64 * XS_LDW;
-    const int lrow = L.lrow();
+    const int lrow = L.lrow(), kp = L.kp();
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int kp = L.kp(i);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int row = lrow + j;
-            uint32_t p0, p1, p2;
-            split3(r[2 * i][j], r[2 * i + 1][j], p0, p1, p2);
-            uint32_t* d = lds + row * XS_LDW + 4 * ((kp >> 2) ^ xs_swz(row)) + (kp & 3);
-            d[0] = p0;
-            d[PL] = p1;
-            d[2 * PL] = p2;
-        }
+    for (int j = 0; j < 4; ++j) {
+        const int row = lrow + j;
+        uint32_t p0, p1, p2;
+        split3(r[0][j], r[1][j], p0, p1, p2);
+        uint32_t* d = lds + row * XS_LDW + 4 * ((kp >> 2) ^ xs_swz(row)) + (kp & 3);
+        d[0] = p0;
+        d[PL] = p1;
+        d[2 * PL] = p2;
     }
 }
 
+// EIGHT waves: wave w multiplies the k-step 16*(w>>1) .. +15 of the row half w & 1 (a 32 x 64 strip: 12 MFMAs per k-tile) and
+// stages an eighth of the tile (16 floats per thread).  Four waves per block ran every k-tile as 24 MFMAs + a 32-float
+// split per thread back to back, ~2 500 cycles with nothing else on the CU; halving both is what the small products
+// (125 workgroups on 256 CUs) respond to.
 template <bool A_KC, bool B_KC>
-__global__ __launch_bounds__(256, 2) void gemm_x3s_kernel(const GemmParams p) {
+__global__ __launch_bounds__(XS_NT, 1) void gemm_x3s_kernel(const GemmParams p) {
     constexpr int PL = 64 * XS_LDW;                        // dwords per plane
     __shared__ __attribute__((aligned(16))) uint32_t smem[6 * PL];   // A planes 0..2, B planes 0..2 (49 152 B); reused by the final exchange
     uint32_t* As = smem;
@@ -1413,6 +1396,7 @@ __global__ __launch_bounds__(256, 2) void gemm_x3s_kernel(const GemmParams p) {
     const int lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, h = lane >> 5;
+    const int kstep = wid >> 1, rh = wid & 1;              // this wave's k-step inside a k-tile, and its row half
 
     const int tiles_n = (p.N + 63) / 64;
     const int tiles_m = (p.M + 63) / 64;
@@ -1433,19 +1417,16 @@ __global__ __launch_bounds__(256, 2) void gemm_x3s_kernel(const GemmParams p) {
     const int kt_begin = ks * kt_per;
     const int kt_end = min(kt_total, kt_begin + kt_per);
 
-    f32x16 acc[2][2];
+    f32x16 acc[2];                                         // tiles (rh, 0) and (rh, 1), partial over this wave's k-steps
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int j = 0; j < 2; ++j)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+        for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
 
-    // THREE register sets: with 125 workgroups on 256 CUs nothing else hides a k-tile's load latency (one set: 19 k-tiles
-    // of a K = 1200 product cost 19 exposed L2/HBM round trips, 29 us), so the loads of tiles t+1 .. t+3 are in flight
-    // while tile t is multiplied.  Tile t travels through set t % 3; indices past the last tile are clamped (a redundant,
-    // unused load) so that the loop body has no branch around a load and every wait stays a counted one.
-    f32x4 ra[3][4], rb[3][4];
+    // THREE register sets: the loads of tiles t+1 .. t+3 are in flight while tile t is multiplied.  Tile t travels through
+    // set t % 3; indices past the last tile are clamped (a redundant, unused load) so that the loop body has no branch
+    // around a load and every wait stays a counted one.
+    f32x4 ra[3][2], rb[3][2];
     LoaderKCS lkA, lkB; LoaderRMS lrA, lrB;
     const int convA = (A_KC && p.conv_on == 1) ? p.conv_T : 0;
     const int convB = (!B_KC && p.conv_on == 2) ? p.conv_T : 0;
@@ -1469,30 +1450,31 @@ __global__ __launch_bounds__(256, 2) void gemm_x3s_kernel(const GemmParams p) {
         if constexpr (A_KC) store_kc_xs(As, ra[S], tid);
         else {
             store_rm_xs(As, ra[S], lrA);
-            if (do_csum) cs += (ra[S][0] + ra[S][1]) + (ra[S][2] + ra[S][3]);
+            if (do_csum) cs += ra[S][0] + ra[S][1];
         }
         if constexpr (B_KC) store_kc_xs(Bs, rb[S], tid); else store_rm_xs(Bs, rb[S], lrB);
     };
     auto compute = [&]() {
-        bf16x8 fa[2][3], fb[2][3];
+        bf16x8 fa[3], fb[2][3];
+        {
+            const int row = rh * 32 + l31;
+            const int q4 = 4 * ((2 * kstep + h) ^ xs_swz(row));
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int row = i * 32 + l31;
-            const int q4 = 4 * ((2 * wid + h) ^ xs_swz(row));
+            for (int t = 0; t < 3; ++t) fa[t] = *reinterpret_cast<const bf16x8*>(As + t * PL + row * XS_LDW + q4);
+        }
 #pragma unroll
-            for (int t = 0; t < 3; ++t) {
-                fa[i][t] = *reinterpret_cast<const bf16x8*>(As + t * PL + row * XS_LDW + q4);
-                fb[i][t] = *reinterpret_cast<const bf16x8*>(Bs + t * PL + row * XS_LDW + q4);
-            }
+        for (int j = 0; j < 2; ++j) {
+            const int row = j * 32 + l31;
+            const int q4 = 4 * ((2 * kstep + h) ^ xs_swz(row));
+#pragma unroll
+            for (int t = 0; t < 3; ++t) fb[j][t] = *reinterpret_cast<const bf16x8*>(Bs + t * PL + row * XS_LDW + q4);
         }
         constexpr int TA[6] = {0, 2, 1, 0, 1, 0}, TB[6] = {2, 0, 1, 1, 0, 0};      // smallest products first
 #pragma unroll
         for (int t = 0; t < 6; ++t)
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][TA[t]], fb[j][TB[t]], acc[i][j], 0, 0, 0);
+            for (int j = 0; j < 2; ++j)
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[TA[t]], fb[j][TB[t]], acc[j], 0, 0, 0);
     };
     using S0 = std::integral_constant<int, 0>;
     using S1 = std::integral_constant<int, 1>;
@@ -1523,11 +1505,9 @@ __global__ __launch_bounds__(256, 2) void gemm_x3s_kernel(const GemmParams p) {
 
     float* fsm = reinterpret_cast<float*>(smem);
     if (do_csum) {
-        // the k pairs of a column are spread over lanes (c), two units and the waves w, w + 2: shuffles, then LDS
-        // (two addends per slot on top of 0 -> order-independent)
+        // a column's k pairs are spread over the lanes' c and the four waves of its column half: shuffles, then one LDS
+        // slot per (wave pair, column), summed in a fixed order
         float* dst = p.ksplit > 1 ? p.csum_part + (int64_t)ks * p.M : p.csum;
-        if (tid < 64) fsm[tid] = 0.f;
-        __syncthreads();
         if constexpr (!A_KC) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
@@ -1535,43 +1515,42 @@ __global__ __launch_bounds__(256, 2) void gemm_x3s_kernel(const GemmParams p) {
                 v += __shfl_xor(v, 8);
                 v += __shfl_xor(v, 16);
                 v += __shfl_xor(v, 32);
-                if ((lane >> 3) == 0) atomicAdd(&fsm[lrA.lrow() + j], v);
+                if ((lane >> 3) == 0) fsm[(wid >> 1) * 64 + lrA.lrow() + j] = v;
             }
         }
         __syncthreads();
-        if (tid < 64 && m0 + tid < p.M) dst[m0 + tid] = fsm[tid];
+        if (tid < 64 && m0 + tid < p.M) dst[m0 + tid] = ((fsm[tid] + fsm[64 + tid]) + fsm[128 + tid]) + fsm[192 + tid];
         __syncthreads();
     }
 
-    // the four partial blocks meet: wave w finishes the 32 x 32 tile (w >> 1, w & 1) and hands its other three tiles
-    // to their owners through LDS (12 slots of 4 KB = the staging area); summed in wave order 0..3 -> deterministic
+    // the partial strips meet: wave w < 4 finishes the 32 x 32 tile (row half w & 1, column half w >> 1); every wave hands
+    // the tiles it does not finish to their owners through LDS (12 slots of 4 KB = the staging area), which add the four
+    // k-step partials in k-step order -> deterministic
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
-        if (t != wid) {
-            const int slot = t * 3 + (wid < t ? wid : wid - 1);
+    for (int j = 0; j < 2; ++j) {
+        if (kstep != j) {
+            const int slot = (2 * j + rh) * 3 + (kstep < j ? kstep : kstep - 1);
 #pragma unroll
-            for (int r = 0; r < 16; ++r) fsm[slot * 1024 + r * 64 + lane] = acc[t >> 1][t & 1][r];
+            for (int r = 0; r < 16; ++r) fsm[slot * 1024 + r * 64 + lane] = acc[j][r];
         }
     }
     __syncthreads();
+    if (wid >= 4) return;
+    const int jo = wid >> 1;                               // this owner's column half (= its own k-step index)
     f32x16 out[1][1];
     {
-        f32x16 own;
-#pragma unroll
-        for (int t = 0; t < 4; ++t)
-            if (t == wid) own = acc[t >> 1][t & 1];              // wid is wave-uniform: a scalar branch per candidate
+        const f32x16 own = jo == 0 ? acc[0] : acc[1];
         f32x16 sum;
-        bool first = true;
 #pragma unroll
         for (int s_ = 0; s_ < 4; ++s_) {
             f32x16 part;
-            if (s_ == wid) part = own;
+            if (s_ == jo) part = own;
             else {
-                const int slot = wid * 3 + (s_ < wid ? s_ : s_ - 1);
+                const int slot = wid * 3 + (s_ < jo ? s_ : s_ - 1);
 #pragma unroll
                 for (int r = 0; r < 16; ++r) part[r] = fsm[slot * 1024 + r * 64 + lane];
             }
-            if (first) { sum = part; first = false; }
+            if (s_ == 0) sum = part;
             else {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) sum[r] += part[r];
@@ -1582,7 +1561,7 @@ __global__ __launch_bounds__(256, 2) void gemm_x3s_kernel(const GemmParams p) {
 
     const bool partial = p.ksplit > 1;
     float* Cout = partial ? p.C + (int64_t)ks * p.split_stride : p.C;
-    const int mw = m0 + (wid >> 1) * 32, nw = n0 + (wid & 1) * 32;
+    const int mw = m0 + rh * 32, nw = n0 + jo * 32;
     const bool full = (mw + 32 <= p.M) && (nw + 32 <= p.N);
     const bool ub = !partial && p.bias != nullptr;
     const int epi = partial ? EPI_NONE : p.epi;
@@ -1593,7 +1572,7 @@ __global__ __launch_bounds__(256, 2) void gemm_x3s_kernel(const GemmParams p) {
 template <bool A_KC, bool B_KC>
 static int launch_x3s(const GemmParams& p, hipStream_t s) {
     const int tiles = cdiv(p.M, 64) * cdiv(p.N, 64);
-    hipLaunchKernelGGL((gemm_x3s_kernel<A_KC, B_KC>), dim3(tiles * p.ksplit), dim3(256), 0, s, p);
+    hipLaunchKernelGGL((gemm_x3s_kernel<A_KC, B_KC>), dim3(tiles * p.ksplit), dim3(XS_NT), 0, s, p);
     return check_launch("gemm_x3s");
 }
 // products the small-tile split kernel takes: enough 64 x 64 tiles to matter, at least two of its k-tiles
