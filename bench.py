@@ -446,8 +446,9 @@ def main():
                     **pmc_traffic("gemm_split_family"),
                     "launches_per_step": gs["launches_per_step"], "avg_launch_ms": round(gs["ms_per_step"] / max(gs["launches_per_step"], 1), 5),
                     "flops_per_step": gs["work_per_step"],
-                    "other_gemm_launches": {**fam_line(gm), "kernel": "gemm_f32_kernel (v_mfma_f32_32x32x2_f32): products too small for the split kernel's tiles (user tower)",
-                                            "peak": PEAK_F32_MATRIX_TFLOPS, "frac": round(tfl(gm) / PEAK_F32_MATRIX_TFLOPS, 4)},
+                    "other_gemm_launches": {**fam_line(gm), "kernel": "gemm_x3s_kernel (the same arithmetic on 64x64 tiles, eight waves splitting the k-tile): products with too few "
+                                                                      "tiles for gemm_x3_kernel (the user tower's 1 600 rows); latency-bound 125-475-workgroup grids",
+                                            "peak": peak, "frac": round(tfl(gm) / peak, 4)},
                     "all_gemm_launches": {"achieved": round(all_tflops, 2), "ms_per_step": round(all_ms, 4), "flops_per_step": all_flops}}
     else:
         bf16 = args.gemm == "bf16"          # mixed launches then: large products on the bf16 pipe (dense peak 2500 TFLOP/s), the rest fp32

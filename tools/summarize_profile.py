@@ -54,7 +54,7 @@ for k in set(fetch) | set(write) | set(mfma):
         d["mfma_busy_frac"] = round(sum(m["SQ_VALU_MFMA_BUSY_CYCLES"]) / 1024.0 / (sum(m["GRBM_GUI_ACTIVE"]) / 8.0), 4)
 
 summary = {"tag": tag, "kernels": out}
-for fam_name, pat in (("gemm_family", "gemm_f32_kernel"), ("gemm_split_family", "gemm_x3_kernel"), ("gemm_h_family", "gemm_h_kernel")):
+for fam_name, pat in (("gemm_family", "gemm_f32_kernel"), ("gemm_split_family", "gemm_x3_kernel"), ("gemm_split_small_family", "gemm_x3s_kernel"), ("gemm_h_family", "gemm_h_kernel")):
   gemm = {k: v for k, v in out.items() if pat in k}
   n = sum(v.get("calls", 0) for v in gemm.values())
   if n and all("hbm_bytes_per_launch" in v for v in gemm.values()):
