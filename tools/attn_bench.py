@@ -5,6 +5,7 @@ sys.path.insert(0, os.path.join(ROOT, "news-recommendation_amd"))
 import torch
 from newsrec_hip import ops
 N, S, H, dh = (int(v) for v in sys.argv[1:5]) if len(sys.argv) > 4 else (1760, 32, 12, 25)
+p = float(sys.argv[5]) if len(sys.argv) > 5 else 0.0
 D = H * dh
 qkv = torch.randn(N * S, 3 * D, device="cuda")
 mask = torch.ones(N, S, dtype=torch.int64, device="cuda")
@@ -17,11 +18,11 @@ def timeit(fn, n=20):
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / n * 1e3
 q = qkv.clone().requires_grad_(True)
-out = ops.mhsa(q, mask, N, S, H, dh)
-print("fwd us", round(timeit(lambda: ops.mhsa(qkv, mask, N, S, H, dh)), 1))
+out = ops.mhsa(q, mask, N, S, H, dh, p, 1234, 3)
+print("fwd us", round(timeit(lambda: ops.mhsa(qkv, mask, N, S, H, dh, p, 1234, 3)), 1))
 g = torch.randn_like(out)
 def fb():
     q.grad = None
-    o = ops.mhsa(q, mask, N, S, H, dh)
+    o = ops.mhsa(q, mask, N, S, H, dh, p, 1234, 3)
     o.backward(g)
 print("fwd+bwd us", round(timeit(fb), 1))
