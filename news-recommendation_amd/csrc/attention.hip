@@ -237,6 +237,104 @@ __global__ __launch_bounds__(NT) void mhsa_bwd_kernel(const float* __restrict__ 
     lds_to_tile<DHP, LD, NT>(dbase + 2 * A, ld, Gs, S, dh, lane);
 }
 
+// The same backward for shapes whose P / dS staging does not fit the LDS (S = 96 or 128 at head dim 64): phase B
+// RECOMPUTES p_ij and dS_ij from Q, K, V, dO and the per-query (max, sum, D) instead of reading two [S][S+1] tiles, so
+// the LDS need is the four operand tiles, 4*S*(DHP+1) + 4*S floats (135 KB at S = 128, dh = 64).  All four tiles use the
+// odd pitch (a lane reads its OWN row in one phase and broadcast rows in the other).  About twice the arithmetic of
+// the staged kernel and scalar LDS reads: the fallback that lets every shape the forward accepts train, not a fast path.
+template <int DHP, int NT>
+__global__ __launch_bounds__(NT) void mhsa_bwd_recompute_kernel(const float* __restrict__ qkv, const int64_t* __restrict__ mask,
+                                                                const float* __restrict__ ctx, const float* __restrict__ dctx,
+                                                                const float* __restrict__ row_max, const float* __restrict__ row_sum,
+                                                                float* __restrict__ dqkv, int S, int H, int dh, DropoutCfg dc) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int LD = DHP + 1;
+    float* Ks = smem;                 // [S][LD]
+    float* Vs = Ks + S * LD;
+    float* Qs = Vs + S * LD;
+    float* Gs = Qs + S * LD;          // dO tile
+    float* Ms = Gs + S * LD;          // [S] additive key mask
+    float* Mx = Ms + S;               // [S] softmax max of query i
+    float* Sm = Mx + S;               // [S] softmax sum
+    float* Dd = Sm + S;               // [S] D_i = dO_i . O_i
+    const int lane = threadIdx.x;
+    const int n = blockIdx.x / H, h = blockIdx.x - n * H;
+    const int A = H * dh;
+    const int64_t ld = 3 * (int64_t)A;
+    const float* base = qkv + (int64_t)n * S * ld + h * dh;
+    tile_to_lds<DHP, LD, NT>(Qs, base, ld, S, dh, lane);
+    tile_to_lds<DHP, LD, NT>(Ks, base + A, ld, S, dh, lane);
+    tile_to_lds<DHP, LD, NT>(Vs, base + 2 * A, ld, S, dh, lane);
+    tile_to_lds<DHP, LD, NT>(Gs, dctx + (int64_t)n * S * A + h * dh, A, S, dh, lane);
+    const bool live = lane < S;
+    if (live) {
+        Ms[lane] = mask[(int64_t)n * S + lane] ? 0.f : dc.mask_fill;
+        Mx[lane] = row_max[((int64_t)n * H + h) * S + lane];
+        Sm[lane] = row_sum[((int64_t)n * H + h) * S + lane];
+    }
+    __syncthreads();
+    const float sq = sqrtf((float)dh);
+    const uint32_t thr = drop_threshold(dc.p);
+    const float scale = dc.p > 0.f ? 1.0f / (1.0f - dc.p) : 1.0f;
+    float* dbase = dqkv + (int64_t)n * S * ld + h * dh;
+    // ---- phase A: lane = query row i -> dq_i (straight to HBM: no staging tile), D_i
+    if (live) {
+        const int i = lane;
+        float q[DHP], go[DHP], dq[DHP];
+        float Di = 0.f;
+#pragma unroll
+        for (int d = 0; d < DHP; ++d) { q[d] = Qs[i * LD + d]; go[d] = Gs[i * LD + d]; dq[d] = 0.f; }
+        const float* orow = ctx + ((int64_t)n * S + i) * A + h * dh;
+        for (int d = 0; d < dh; ++d) Di = fmaf(go[d], orow[d], Di);
+        Dd[i] = Di;
+        const float m = Mx[i], sum = Sm[i];
+        const int64_t row_linear = ((int64_t)n * H + h) * S + i;
+        for (int j = 0; j < S; ++j) {
+            float acc = 0.f, dpd = 0.f;
+#pragma unroll
+            for (int d = 0; d < DHP; ++d) { acc = fmaf(q[d], Ks[j * LD + d], acc); dpd = fmaf(go[d], Vs[j * LD + d], dpd); }
+            float x = acc / sq;
+            x += Ms[j];
+            const float p = expf(x - m) / sum;
+            float pd = p;
+            if (dc.p > 0.f) pd *= keep_scale(dc, thr, scale, row_linear, S, j);
+            const float ds = (pd * dpd - p * Di) / sq;
+#pragma unroll
+            for (int d = 0; d < DHP; ++d) dq[d] = fmaf(ds, Ks[j * LD + d], dq[d]);
+        }
+        for (int d = 0; d < dh; ++d) dbase[(int64_t)i * ld + d] = dq[d];
+    }
+    __syncthreads();                  // D_i visible
+    // ---- phase B: lane = key row j -> dk_j, dv_j with p_ij / dS_ij recomputed (same expressions, same operand order)
+    if (live) {
+        const int j = lane;
+        float dk[DHP], dv[DHP];
+#pragma unroll
+        for (int d = 0; d < DHP; ++d) { dk[d] = 0.f; dv[d] = 0.f; }
+        const float mj = Ms[j];
+        for (int i = 0; i < S; ++i) {
+            float acc = 0.f, dpd = 0.f;
+#pragma unroll
+            for (int d = 0; d < DHP; ++d) { acc = fmaf(Qs[i * LD + d], Ks[j * LD + d], acc); dpd = fmaf(Gs[i * LD + d], Vs[j * LD + d], dpd); }
+            float x = acc / sq;
+            x += mj;
+            const float p = expf(x - Mx[i]) / Sm[i];
+            float pd = p;
+            if (dc.p > 0.f) pd *= keep_scale(dc, thr, scale, ((int64_t)n * H + h) * S + i, S, j);
+            const float ds = (pd * dpd - p * Dd[i]) / sq;
+#pragma unroll
+            for (int d = 0; d < DHP; ++d) {
+                dk[d] = fmaf(ds, Qs[i * LD + d], dk[d]);
+                dv[d] = fmaf(pd, Gs[i * LD + d], dv[d]);
+            }
+        }
+        for (int d = 0; d < dh; ++d) {
+            dbase[A + (int64_t)j * ld + d] = dk[d];
+            dbase[2 * A + (int64_t)j * ld + d] = dv[d];
+        }
+    }
+}
+
 constexpr size_t MHSA_LDS_MAX = 160 * 1024;    // one workgroup may take the CU's whole LDS
 static int pick_dhp(int dh) { return dh <= 32 ? 32 : (dh <= 64 ? 64 : (dh <= 128 ? 128 : 0)); }
 
@@ -278,10 +376,24 @@ int mhsa_bwd(const float* qkv, const int64_t* mask, const float* ctx, const floa
     NR_UNSUPPORTED(S > 128 || S < 1, "mhsa bwd: sequence length %d not in [1,128]", S);
     const int dhp = pick_dhp(dh);
     NR_UNSUPPORTED(dhp == 0 || dhp > 64, "mhsa bwd: head dim %d > 64", dh);
-    const size_t lds = (size_t)(2 * S * dhp + 3 * S * (dhp + 1) + 2 * S * (S + 1) + S) * sizeof(float);
-    NR_UNSUPPORTED(lds > MHSA_LDS_MAX, "mhsa bwd: S=%d with head dim %d needs %zu B of LDS (> %zu)", S, dh, lds, MHSA_LDS_MAX);
+    size_t lds = (size_t)(2 * S * dhp + 3 * S * (dhp + 1) + 2 * S * (S + 1) + S) * sizeof(float);
     ProfScope prof(FAM_ATTN, s, 10.0 * N * H * S * S * dh);
     const dim3 grid((unsigned)(N * H));
+    if (lds > MHSA_LDS_MAX) {
+        // the P / dS staging tiles do not fit (S = 96 / 128 at head dim 64): the recompute kernel needs the operand tiles only
+        lds = (size_t)(4 * S * (dhp + 1) + 4 * S) * sizeof(float);
+        NR_UNSUPPORTED(lds > MHSA_LDS_MAX, "mhsa bwd: S=%d with head dim %d needs %zu B of LDS (> %zu)", S, dh, lds, MHSA_LDS_MAX);
+#define NR_BWD_R(P, T)                                                                                              \
+    do {                                                                                                            \
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mhsa_bwd_recompute_kernel<P, T>),                  \
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                            \
+        hipLaunchKernelGGL((mhsa_bwd_recompute_kernel<P, T>), grid, dim3(T), lds, s, qkv, mask, ctx, dctx, row_max, row_sum, dqkv, S, H, dh, dc); \
+    } while (0)
+        if (S <= 64) { if (dhp == 32) NR_BWD_R(32, 64); else NR_BWD_R(64, 64); }
+        else         { if (dhp == 32) NR_BWD_R(32, 128); else NR_BWD_R(64, 128); }
+#undef NR_BWD_R
+        return check_launch("mhsa_bwd_recompute");
+    }
 #define NR_BWD(P, T)                                                                                                \
     do {                                                                                                            \
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mhsa_bwd_kernel<P, T>),                            \
