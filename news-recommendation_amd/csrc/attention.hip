@@ -345,6 +345,10 @@ int mhsa_fwd(const float* qkv, const int64_t* mask, float* ctx, float* row_max, 
         ProfScope prof(FAM_ATTN, s, 4.0 * N * H * S * S * dh);
         return mhsa_fwd_mfma(qkv, mask, ctx, row_max, row_sum, N, S, H, dh, dc, s);
     }
+    if (mhsa_mfma2_supported(S, dh) && !dc.offs) {
+        ProfScope prof(FAM_ATTN, s, 4.0 * N * H * S * S * dh);
+        return mhsa_fwd_mfma2(qkv, mask, ctx, row_max, row_sum, N, S, H, dh, dc, s);
+    }
     NR_UNSUPPORTED(dc.offs != nullptr, "mhsa: packed sequences need S <= 32 and head dim <= 64 (got S=%d, dh=%d)", S, dh);
     NR_UNSUPPORTED(S > 128 || S < 1, "mhsa: sequence length %d not in [1,128]", S);
     const int dhp = pick_dhp(dh);
@@ -371,6 +375,10 @@ int mhsa_bwd(const float* qkv, const int64_t* mask, const float* ctx, const floa
     if (mhsa_mfma_supported(S, dh)) {
         ProfScope prof(FAM_ATTN, s, 10.0 * N * H * S * S * dh);
         return mhsa_bwd_mfma(qkv, mask, dctx, row_max, row_sum, dqkv, N, S, H, dh, dc, s);
+    }
+    if (mhsa_mfma2_supported(S, dh) && !dc.offs) {
+        ProfScope prof(FAM_ATTN, s, 10.0 * N * H * S * S * dh);
+        return mhsa_bwd_mfma2(qkv, mask, dctx, row_max, row_sum, dqkv, N, S, H, dh, dc, s);
     }
     NR_UNSUPPORTED(dc.offs != nullptr, "mhsa bwd: packed sequences need S <= 32 and head dim <= 64 (got S=%d, dh=%d)", S, dh);
     NR_UNSUPPORTED(S > 128 || S < 1, "mhsa bwd: sequence length %d not in [1,128]", S);

@@ -19,59 +19,38 @@
 // Dropout keep bits are drawn once, in the T orientation (4 consecutive keys share one Philox call
 // when S % 4 == 0), and handed to the N orientation as a 32-bit word per query through LDS.
 #include "common.h"
-#include <cstdlib>
 #include "seqops.h"
 
 namespace nr {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+#ifdef NR_ATTN_STAMP          // diagnostic build: cycle stamps of wave 0 of every workgroup (tools/attn_stamps.py)
+__device__ unsigned long long attn_stamps[4096 * 16];
+#define AT_STAMP(i) do { if (threadIdx.x == 0 && blockIdx.x < 4096) attn_stamps[blockIdx.x * 16 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#define AT_STAMP_RT(i) do { if (threadIdx.x == 0 && blockIdx.x < 4096) attn_stamps[blockIdx.x * 16 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define AT_STAMP(i) do {} while (0)
+#define AT_STAMP_RT(i) do {} while (0)
+#endif
 constexpr int HPG = 4;                 // heads per workgroup
 
 __device__ __forceinline__ int krow(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
 __device__ __forceinline__ int fastdiv(int x, int inv20) { return (int)(((unsigned)x * (unsigned)inv20) >> 20); }   // x < 16384/d
 
-// zero what the MFMAs read but the copy does not write: rows >= S, and the odd-dh pad column
-template <int DHP>
+// zero what the MFMAs read but the copy does not write: rows >= S, and the columns dh .. dz-1 (the d loop runs in groups
+// of 4 steps = 8 columns, so dz = dh rounded up to 8)
+template <int DHP, int ROWS = 32>
 __device__ __forceinline__ void tile_zero_pad(float* tile, int S, int dh, int lane) {
     constexpr int LD = DHP + 1;
-    const int dz = ((dh + 1) >> 1) * 2;          // columns read by the d-step loop
-    if (dz > dh && lane < 32) tile[lane * LD + dh] = 0.f;
-    for (int idx = lane; idx < (32 - S) * dz; idx += 64) {
+    const int dz = ((dh + 7) >> 3) * 8;
+    if (lane < ROWS) for (int c = dh; c < dz; ++c) tile[lane * LD + c] = 0.f;
+    for (int idx = lane; idx < (ROWS - S) * dz; idx += 64) {
         const int r = S + idx / dz, c = idx - (idx / dz) * dz;
         tile[r * LD + c] = 0.f;
     }
 }
 
-// [S rows] x [nh*dh] global segment (row stride ld) -> nh per-head tiles [32][LD]
-template <int DHP>
-__device__ __forceinline__ void heads_in(float* tiles, const float* __restrict__ g, int64_t ld, int S, int dh, int nh, int tid, bool vec, int nthr = 256) {
-    constexpr int LD = DHP + 1, TS = 32 * LD;
-    const int W = nh * dh;
-    const int inv_dh = (1048576 + dh - 1) / dh;
-    if (vec) {
-        const int nq = W >> 2;
-        const int inv_nq = (1048576 + nq - 1) / nq;
-        for (int idx = tid; idx < S * nq; idx += nthr) {
-            const int r = fastdiv(idx, inv_nq);
-            const int c = (idx - r * nq) << 2;
-            const float4 v = *reinterpret_cast<const float4*>(g + (int64_t)r * ld + c);
-            int hh = fastdiv(c, inv_dh), d = c - hh * dh;
-            const float e[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                tiles[hh * TS + r * LD + d] = e[k];
-                if (++d == dh) { d = 0; ++hh; }
-            }
-        }
-    } else {
-        for (int idx = tid; idx < S * W; idx += nthr) {
-            const int r = idx / W;
-            const int c = idx - r * W;
-            const int hh = fastdiv(c, inv_dh);
-            tiles[hh * TS + r * LD + (c - hh * dh)] = g[(int64_t)r * ld + c];
-        }
-    }
-}
+// [S rows] x [nh*dh] global segment (row stride ld) -> nh per-head tiles [32][LD], bf16 tensor
 // the same for a bf16 tensor (the bf16 build keeps qkv / ctx and their gradients as bf16 in HBM; the tiles and all the
 // arithmetic stay f32): 16-byte pieces of 8 elements when the segment allows it
 template <int DHP>
@@ -103,6 +82,64 @@ __device__ __forceinline__ void heads_in(float* tiles, const unsigned short* __r
         }
     }
 }
+// NSRC segments at once (q, k, v [, dO] of the same rows): the loads of one iteration are all in flight before the
+// first scatter, so the workgroup pays one HBM round trip for its operands, not NSRC.  vec = 4 / 2: 16- / 8-byte pieces.
+template <int DHP, int ROWS, int NSRC, int VW>
+__device__ __forceinline__ void heads_in_vec(float* const (&tiles)[NSRC], const float* const (&g)[NSRC], const int64_t (&ld)[NSRC],
+                                             int S, int dh, int nh, int tid, int nthr) {
+    typedef float vt __attribute__((ext_vector_type(VW)));
+    constexpr int LD = DHP + 1, TS = ROWS * LD;
+    const int inv_dh = (1048576 + dh - 1) / dh;
+    const int nq = (nh * dh) / VW;
+    const int inv_nq = (1048576 + nq - 1) / nq;
+    for (int idx = tid; idx < S * nq; idx += nthr) {
+        const int r = fastdiv(idx, inv_nq);
+        const int c = (idx - r * nq) * VW;
+        vt v[NSRC];
+#pragma unroll
+        for (int k = 0; k < NSRC; ++k) v[k] = *reinterpret_cast<const vt*>(g[k] + (int64_t)r * ld[k] + c);
+        int hh = fastdiv(c, inv_dh), d = c - hh * dh;
+        int off[VW];
+#pragma unroll
+        for (int e = 0; e < VW; ++e) {
+            off[e] = hh * TS + r * LD + d;
+            if (++d == dh) { d = 0; ++hh; }
+        }
+#pragma unroll
+        for (int k = 0; k < NSRC; ++k)
+#pragma unroll
+            for (int e = 0; e < VW; ++e) tiles[k][off[e]] = v[k][e];
+    }
+}
+template <int DHP, int ROWS, int NSRC>
+__device__ __forceinline__ void heads_in_n(float* const (&tiles)[NSRC], const float* const (&g)[NSRC], const int64_t (&ld)[NSRC],
+                                           int S, int dh, int nh, int tid, int vec, int nthr) {
+    if (vec == 4) heads_in_vec<DHP, ROWS, NSRC, 4>(tiles, g, ld, S, dh, nh, tid, nthr);
+    else if (vec == 2) heads_in_vec<DHP, ROWS, NSRC, 2>(tiles, g, ld, S, dh, nh, tid, nthr);
+    else {
+        constexpr int LD = DHP + 1, TS = ROWS * LD;
+        const int W = nh * dh;
+        const int inv_dh = (1048576 + dh - 1) / dh;
+        for (int idx = tid; idx < S * W; idx += nthr) {
+            const int r = idx / W;
+            const int c = idx - r * W;
+            const int hh = fastdiv(c, inv_dh);
+            float v[NSRC];
+#pragma unroll
+            for (int k = 0; k < NSRC; ++k) v[k] = g[k][(int64_t)r * ld[k] + c];
+#pragma unroll
+            for (int k = 0; k < NSRC; ++k) tiles[k][hh * TS + r * LD + (c - hh * dh)] = v[k];
+        }
+    }
+}
+// bf16 tensors: one segment after the other
+template <int DHP, int ROWS, int NSRC>
+__device__ __forceinline__ void heads_in_n(float* const (&tiles)[NSRC], const unsigned short* const (&g)[NSRC], const int64_t (&ld)[NSRC],
+                                           int S, int dh, int nh, int tid, int vec, int nthr) {
+#pragma unroll
+    for (int k = 0; k < NSRC; ++k) heads_in<DHP>(tiles[k], g[k], ld[k], S, dh, nh, tid, vec != 0, nthr);
+}
+
 typedef __bf16 abf16x2 __attribute__((ext_vector_type(2)));
 typedef float af32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ uint32_t apack2(float lo, float hi) {
@@ -110,7 +147,7 @@ __device__ __forceinline__ uint32_t apack2(float lo, float hi) {
     return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, abf16x2));
 }
 template <int DHP>
-__device__ __forceinline__ void heads_out(unsigned short* __restrict__ g, int64_t ld, const float* tiles, int S, int dh, int nh, int tid, bool vec, int nthr = 256) {
+__device__ __forceinline__ void heads_out(unsigned short* __restrict__ g, int64_t ld, const float* tiles, int S, int dh, int nh, int tid, int vec, int nthr = 256) {
     constexpr int LD = DHP + 1, TS = 32 * LD;
     const int W = nh * dh;
     const int inv_dh = (1048576 + dh - 1) / dh;
@@ -138,27 +175,34 @@ __device__ __forceinline__ void heads_out(unsigned short* __restrict__ g, int64_
     }
 }
 
-template <int DHP>
-__device__ __forceinline__ void heads_out(float* __restrict__ g, int64_t ld, const float* tiles, int S, int dh, int nh, int tid, bool vec, int nthr = 256) {
-    constexpr int LD = DHP + 1, TS = 32 * LD;
-    const int W = nh * dh;
+template <int DHP, int ROWS, int VW>
+__device__ __forceinline__ void heads_out_vec(float* __restrict__ g, int64_t ld, const float* tiles, int S, int dh, int nh, int tid, int nthr) {
+    typedef float vt __attribute__((ext_vector_type(VW)));
+    constexpr int LD = DHP + 1, TS = ROWS * LD;
     const int inv_dh = (1048576 + dh - 1) / dh;
-    if (vec) {
-        const int nq = W >> 2;
-        const int inv_nq = (1048576 + nq - 1) / nq;
-        for (int idx = tid; idx < S * nq; idx += nthr) {
-            const int r = fastdiv(idx, inv_nq);
-            const int c = (idx - r * nq) << 2;
-            int hh = fastdiv(c, inv_dh), d = c - hh * dh;
-            float e[4];
+    const int nq = (nh * dh) / VW;
+    const int inv_nq = (1048576 + nq - 1) / nq;
+    for (int idx = tid; idx < S * nq; idx += nthr) {
+        const int r = fastdiv(idx, inv_nq);
+        const int c = (idx - r * nq) * VW;
+        int hh = fastdiv(c, inv_dh), d = c - hh * dh;
+        vt e;
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                e[k] = tiles[hh * TS + r * LD + d];
-                if (++d == dh) { d = 0; ++hh; }
-            }
-            *reinterpret_cast<float4*>(g + (int64_t)r * ld + c) = make_float4(e[0], e[1], e[2], e[3]);
+        for (int k = 0; k < VW; ++k) {
+            e[k] = tiles[hh * TS + r * LD + d];
+            if (++d == dh) { d = 0; ++hh; }
         }
-    } else {
+        *reinterpret_cast<vt*>(g + (int64_t)r * ld + c) = e;
+    }
+}
+template <int DHP, int ROWS = 32>
+__device__ __forceinline__ void heads_out(float* __restrict__ g, int64_t ld, const float* tiles, int S, int dh, int nh, int tid, int vec, int nthr = 256) {
+    if (vec == 4) heads_out_vec<DHP, ROWS, 4>(g, ld, tiles, S, dh, nh, tid, nthr);
+    else if (vec == 2) heads_out_vec<DHP, ROWS, 2>(g, ld, tiles, S, dh, nh, tid, nthr);
+    else {
+        constexpr int LD = DHP + 1, TS = ROWS * LD;
+        const int W = nh * dh;
+        const int inv_dh = (1048576 + dh - 1) / dh;
         for (int idx = tid; idx < S * W; idx += nthr) {
             const int r = idx / W;
             const int c = idx - r * W;
@@ -168,17 +212,23 @@ __device__ __forceinline__ void heads_out(float* __restrict__ g, int64_t ld, con
     }
 }
 
-// acc[r] = sum_d X[row(r,h)][d] * Y[l31][d]  i.e. tile = X . Y^T with row = X's row, col = Y's row
+// acc[r] = sum_d X[row(r,h)][d] * Y[l31][d]  i.e. tile = X . Y^T with row = X's row, col = Y's row.  The d loop runs in
+// groups of 4 k-steps (8 columns, zero-padded by tile_zero_pad): the 8 LDS reads of a group are issued together, so the
+// MFMA chain does not wait one LDS round trip per step.
 template <int DHP>
-__device__ __forceinline__ f32x16 tile_xyT(const float* Xs, const float* Ys, int dsteps, int l31, int h) {
+__device__ __forceinline__ f32x16 tile_xyT(const float* Xs, const float* Ys, int dgroups, int l31, int h) {
     constexpr int LD = DHP + 1;
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-    for (int s = 0; s < dsteps; ++s) {
-        const float a = Xs[l31 * LD + 2 * s + h];
-        const float b = Ys[l31 * LD + 2 * s + h];
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+    const float* xp = Xs + l31 * LD + h;
+    const float* yp = Ys + l31 * LD + h;
+    for (int g = 0; g < dgroups; ++g) {
+        float a[4], b[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { a[u] = xp[8 * g + 2 * u]; b[u] = yp[8 * g + 2 * u]; }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u], b[u], acc, 0, 0, 0);
     }
     return acc;
 }
@@ -196,6 +246,17 @@ __device__ __forceinline__ f32x16 zT_tile(const float* Zs, const f32x16& tile, i
         o = __builtin_amdgcn_mfma_f32_32x32x2f32(a, tile[s], o, 0, 0, 0);
     }
     return o;
+}
+
+// the same, added to o (a second 32-row tile of the summed index)
+template <int DHP>
+__device__ __forceinline__ void zT_tile_acc(f32x16& o, const float* Zs, const f32x16& tile, int dt, int l31, int h) {
+    constexpr int LD = DHP + 1;
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {
+        const float a = Zs[krow(s, h) * LD + dt * 32 + l31];
+        o = __builtin_amdgcn_mfma_f32_32x32x2f32(a, tile[s], o, 0, 0, 0);
+    }
 }
 
 // result tile rows = feature d (dt*32 + row(r,h)), col = sequence position l31 -> LDS [pos][d]
@@ -230,6 +291,27 @@ __device__ __forceinline__ unsigned keep_bits16(const DropoutCfg& dc, uint32_t t
     return bits;
 }
 
+// 64-bit keep word of query row `qrow` (bit j = keep key j, j < S <= 64): the two lanes of a query split the row's
+// Philox counters between them (any S: the counters need not start on a row boundary) and exchange halves
+__device__ __forceinline__ uint64_t keep_word64(const DropoutCfg& dc, uint32_t thr, int64_t qrow, int S, int h) {
+    const uint64_t i0 = (uint64_t)(qrow * S);
+    const uint64_t c_last = (i0 + S - 1) >> 2;
+    uint64_t word = 0;
+    for (uint64_t c = (i0 >> 2) + h; c <= c_last; c += 2) {
+        const Philox4 rn = philox4x32_10(dc.seed, c, dc.site);
+        const uint32_t v[4] = {rn.x, rn.y, rn.z, rn.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int64_t j = (int64_t)(4 * c + e) - (int64_t)i0;
+            if (j >= 0 && j < S && v[e] >= thr) word |= 1ull << j;
+        }
+    }
+    uint32_t lo = (uint32_t)word, hi = (uint32_t)(word >> 32);
+    lo |= __shfl_xor(lo, 32, 64);
+    hi |= __shfl_xor(hi, 32, 64);
+    return ((uint64_t)hi << 32) | lo;
+}
+
 template <int DHP, typename T, int NHG>
 __global__ __launch_bounds__(64 * NHG) void mhsa_fwd_mfma_kernel(const T* __restrict__ qkv, const int64_t* __restrict__ mask,
                                                             T* __restrict__ ctx, float* __restrict__ row_max,
@@ -254,23 +336,26 @@ __global__ __launch_bounds__(64 * NHG) void mhsa_fwd_mfma_kernel(const T* __rest
     const int Sn = dc.offs ? dc.offs[n + 1] - dc.offs[n] : S;
     if (Sn == 0) return;                                        // a title with no rows (block-uniform)
     const T* base = qkv + row0 * ld + hd0 * dh;
-    heads_in<DHP>(Qt, base, ld, Sn, dh, nh, tid, vec, 64 * NHG);
-    heads_in<DHP>(Kt, base + A, ld, Sn, dh, nh, tid, vec, 64 * NHG);
-    heads_in<DHP>(Vt, base + 2 * A, ld, Sn, dh, nh, tid, vec, 64 * NHG);
+    float* Mk = Vt + NHG * TS;         // [32] additive key-mask term of this sequence (one global read per key)
+    if (tid < 32) Mk[tid] = tid < Sn ? (mask[(int64_t)n * S + tid] ? 0.f : dc.mask_fill) : -INFINITY;
+    {
+        float* const tl[3] = {Qt, Kt, Vt};
+        const T* const gp[3] = {base, base + A, base + 2 * A};
+        const int64_t lds3[3] = {ld, ld, ld};
+        heads_in_n<DHP, 32, 3>(tl, gp, lds3, Sn, dh, nh, tid, vec, 64 * NHG);
+    }
     float* Qs = Qt + w * TS; float* Ks = Kt + w * TS; float* Vs = Vt + w * TS;
     if (active) { tile_zero_pad<DHP>(Qs, Sn, dh, lane); tile_zero_pad<DHP>(Ks, Sn, dh, lane); tile_zero_pad<DHP>(Vs, Sn, dh, lane); }
     __syncthreads();
     f32x16 st;
     if (active) {
-        const int dsteps = (dh + 1) >> 1;
-        const float sq = sqrtf((float)dh);
+        const int dsteps = (dh + 7) >> 3;                     // groups of 4 k-steps
+        const float sq = sqrtf((float)dh), rsq = 1.0f / sq;
         st = tile_xyT<DHP>(Ks, Qs, dsteps, l31, h);           // row = key, col = query (this lane's query = l31)
         float m = -INFINITY;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const int j = krow(r, h);
-            float x = st[r] / sq;
-            x += (j < Sn) ? (mask[(int64_t)n * S + j] ? 0.f : dc.mask_fill) : -INFINITY;
+            const float x = div_by(st[r], sq, rsq) + Mk[krow(r, h)];
             st[r] = x;
             m = fmaxf(m, x);
         }
@@ -290,9 +375,10 @@ __global__ __launch_bounds__(64 * NHG) void mhsa_fwd_mfma_kernel(const T* __rest
         unsigned bits = 0xFFFFu;
         float scale = 1.f;
         if (dc.p > 0.f) { bits = keep_bits16(dc, drop_threshold(dc.p), qrow, S, h); scale = 1.0f / (1.0f - dc.p); }
+        const float rsum = 1.0f / sum;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            float p = st[r] / sum;
+            float p = div_by(st[r], sum, rsum);
             if (dc.p > 0.f) p = ((bits >> r) & 1u) ? p * scale : 0.f;
             st[r] = p;
         }
@@ -321,7 +407,7 @@ __global__ __launch_bounds__(64 * NHG) void mhsa_bwd_mfma_kernel(const T* __rest
     float* Kt = Qt + NHG * TS;
     float* Vt = Kt + NHG * TS;
     float* Gt = Vt + NHG * TS;
-    float* St = Gt + NHG * TS;          // [NHG][4][32]: max, sum, D, key-mask term ; then [NHG][32] keep words
+    float* St = Gt + NHG * TS;          // [NHG][5][32]: max, sum, D, key-mask term, 1/sum ; then [NHG][32] keep words
     const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63, l31 = lane & 31, h = lane >> 5;
     const int groups = (H + NHG - 1) / NHG;
     const int n = blockIdx.x / groups, gidx = blockIdx.x - n * groups;
@@ -333,13 +419,15 @@ __global__ __launch_bounds__(64 * NHG) void mhsa_bwd_mfma_kernel(const T* __rest
     const int Sn = dc.offs ? dc.offs[n + 1] - dc.offs[n] : S;
     if (Sn == 0) return;
     const T* base = qkv + row0 * ld + hd0 * dh;
-    heads_in<DHP>(Qt, base, ld, Sn, dh, nh, tid, vec, 64 * NHG);
-    heads_in<DHP>(Kt, base + A, ld, Sn, dh, nh, tid, vec, 64 * NHG);
-    heads_in<DHP>(Vt, base + 2 * A, ld, Sn, dh, nh, tid, vec, 64 * NHG);
-    heads_in<DHP>(Gt, dctx + row0 * A + hd0 * dh, A, Sn, dh, nh, tid, vec, 64 * NHG);
+    {
+        float* const tl[4] = {Qt, Kt, Vt, Gt};
+        const T* const gp[4] = {base, base + A, base + 2 * A, dctx + row0 * A + hd0 * dh};
+        const int64_t lds4[4] = {ld, ld, ld, (int64_t)A};
+        heads_in_n<DHP, 32, 4>(tl, gp, lds4, Sn, dh, nh, tid, vec, 64 * NHG);
+    }
     float* Qs = Qt + w * TS; float* Ks = Kt + w * TS; float* Vs = Vt + w * TS; float* Gs = Gt + w * TS;
-    float* Ms = St + w * 128; float* Ls = Ms + 32; float* Dsh = Ms + 64; float* Mk = Ms + 96;
-    unsigned* Kb = reinterpret_cast<unsigned*>(St + NHG * 128) + w * 32;
+    float* Ms = St + w * 160; float* Ls = Ms + 32; float* Dsh = Ms + 64; float* Mk = Ms + 96; float* Rl = Ms + 128;   // Rl = 1 / Ls
+    unsigned* Kb = reinterpret_cast<unsigned*>(St + NHG * 160) + w * 32;
     const int64_t qrow0 = ((int64_t)n * H + hd) * S;
     if (active) {
         tile_zero_pad<DHP>(Qs, Sn, dh, lane); tile_zero_pad<DHP>(Ks, Sn, dh, lane);
@@ -347,20 +435,21 @@ __global__ __launch_bounds__(64 * NHG) void mhsa_bwd_mfma_kernel(const T* __rest
         if (lane < 32) {
             const bool ok = lane < Sn;
             Ms[lane] = ok ? row_max[qrow0 + lane] : 0.f;
-            Ls[lane] = ok ? row_sum[qrow0 + lane] : 1.f;
+            const float l = ok ? row_sum[qrow0 + lane] : 1.f;
+            Ls[lane] = l; Rl[lane] = 1.0f / l;
             Mk[lane] = ok ? (mask[(int64_t)n * S + lane] ? 0.f : dc.mask_fill) : -INFINITY;
         }
     }
     __syncthreads();
-    const int dsteps = (dh + 1) >> 1;
-    const float sq = sqrtf((float)dh);
+    const int dsteps = (dh + 7) >> 3;                     // groups of 4 k-steps
+    const float sq = sqrtf((float)dh), rsq = 1.0f / sq;
     const float scale = dc.p > 0.f ? 1.0f / (1.0f - dc.p) : 1.0f;
     f32x16 dq[DT], ds, pdn;
     if (active) {
         // ---------------- T orientation: row = key, col = query (lane's query = l31)
         f32x16 st = tile_xyT<DHP>(Ks, Qs, dsteps, l31, h);
         const f32x16 dpt = tile_xyT<DHP>(Vs, Gs, dsteps, l31, h);   // dPd^T[key][query] = V[key].dO[query]
-        const float m = Ms[l31], sum = Ls[l31];
+        const float m = Ms[l31], sum = Ls[l31], rsum = Rl[l31];
         unsigned bits = 0xFFFFu;
         if (dc.p > 0.f) {
             bits = keep_bits16(dc, drop_threshold(dc.p), qrow0 + l31, S, h);
@@ -375,8 +464,8 @@ __global__ __launch_bounds__(64 * NHG) void mhsa_bwd_mfma_kernel(const T* __rest
         float dpart = 0.f;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const float x = st[r] / sq + Mk[krow(r, h)];
-            const float p = expf(x - m) / sum;
+            const float x = div_by(st[r], sq, rsq) + Mk[krow(r, h)];
+            const float p = div_by(expf(x - m), sum, rsum);
             const float pd = (dc.p > 0.f) ? (((bits >> r) & 1u) ? p * scale : 0.f) : p;
             pr[r] = p;
             st[r] = pd * dpt[r];                               // Pd * dPd
@@ -385,7 +474,7 @@ __global__ __launch_bounds__(64 * NHG) void mhsa_bwd_mfma_kernel(const T* __rest
         const float D = dpart + __shfl_xor(dpart, 32, 64);
         if (h == 0) Dsh[l31] = D;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) st[r] = (st[r] - pr[r] * D) / sq;      // dS^T
+        for (int r = 0; r < 16; ++r) st[r] = div_by(st[r] - pr[r] * D, sq, rsq);      // dS^T
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt) dq[dt] = zT_tile<DHP>(Ks, st, dt, l31, h);   // dQ^T[d][query], kept in registers
     }
@@ -398,12 +487,12 @@ __global__ __launch_bounds__(64 * NHG) void mhsa_bwd_mfma_kernel(const T* __rest
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int i = krow(r, h);
-            const float x = ds[r] / sq + mk;
-            const float p = expf(x - Ms[i]) / Ls[i];
+            const float x = div_by(ds[r], sq, rsq) + mk;
+            const float p = div_by(expf(x - Ms[i]), Ls[i], Rl[i]);
             float pd = p;
             if (dc.p > 0.f) pd = ((Kb[i] >> l31) & 1u) ? p * scale : 0.f;
             pdn[r] = pd;
-            ds[r] = (pd * dpn[r] - p * Dsh[i]) / sq;           // dS[query][key]
+            ds[r] = div_by(pd * dpn[r] - p * Dsh[i], sq, rsq);           // dS[query][key]
         }
     }
     __syncthreads();                                           // K and V tiles are dead: reuse them as staging
@@ -431,7 +520,250 @@ __global__ __launch_bounds__(64 * NHG) void mhsa_bwd_mfma_kernel(const T* __rest
     heads_out<DHP>(dbase + 2 * A, ld, Kt, Sn, dh, nh, tid, vec, 64 * NHG);
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// 32 < S <= 64 (the 50-slot user tower): a head is a 2x2 grid of 32x32 score tiles and takes TWO waves.  In the T
+// orientation wave t owns query tile t and both key tiles (the softmax row stays inside one lane pair); in the backward's
+// N orientation wave t owns key tile t and both query tiles.  Products that sum over 64 positions chain the second
+// tile's 16 MFMAs onto the first's accumulator.  Head tiles are [64][LD]; everything else is the S <= 32 kernel.
+template <int DHP, int NHG>
+__global__ __launch_bounds__(128 * NHG) void mhsa_fwd_mfma2_kernel(const float* __restrict__ qkv, const int64_t* __restrict__ mask,
+                                                              float* __restrict__ ctx, float* __restrict__ row_max,
+                                                              float* __restrict__ row_sum, int S, int H, int dh, DropoutCfg dc,
+                                                              int vec) {
+    constexpr int LD = DHP + 1, TS = 64 * LD, HT = 32 * LD, NTHR = 128 * NHG;
+    constexpr int DT = DHP / 32;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* Qt = smem;                  // [NHG][TS]  (reused for the output tiles)
+    float* Kt = Qt + NHG * TS;
+    float* Vt = Kt + NHG * TS;
+    AT_STAMP(0); AT_STAMP_RT(1);
+    const int tid = threadIdx.x, w = tid >> 6, hw = w >> 1, t = w & 1, lane = tid & 63, l31 = lane & 31, h = lane >> 5;
+    const int groups = (H + NHG - 1) / NHG;
+    const int n = blockIdx.x / groups, gidx = blockIdx.x - n * groups;
+    const int hd0 = gidx * NHG, nh = min(NHG, H - hd0), hd = hd0 + hw;
+    const bool active = hw < nh;
+    const int A = H * dh;
+    const int64_t ld = 3 * (int64_t)A;
+    const int64_t row0 = (int64_t)n * S;
+    const float* base = qkv + row0 * ld + hd0 * dh;
+    float* Mk = Vt + NHG * TS;         // [64] additive key-mask term of this sequence
+    if (tid < 64) Mk[tid] = tid < S ? (mask[(int64_t)n * S + tid] ? 0.f : dc.mask_fill) : -INFINITY;
+    {
+        float* const tl[3] = {Qt, Kt, Vt};
+        const float* const gp[3] = {base, base + A, base + 2 * A};
+        const int64_t lds3[3] = {ld, ld, ld};
+        heads_in_n<DHP, 64, 3>(tl, gp, lds3, S, dh, nh, tid, vec, NTHR);
+    }
+    float* Qs = Qt + hw * TS; float* Ks = Kt + hw * TS; float* Vs = Vt + hw * TS;
+    if (active) {
+        if (t == 0) { tile_zero_pad<DHP, 64>(Qs, S, dh, lane); tile_zero_pad<DHP, 64>(Ks, S, dh, lane); }
+        else tile_zero_pad<DHP, 64>(Vs, S, dh, lane);
+    }
+    AT_STAMP(2);
+    __syncthreads();
+    AT_STAMP(3);
+    f32x16 st[2];
+    if (active) {
+        const int dsteps = (dh + 7) >> 3;                     // groups of 4 k-steps
+        const float sq = sqrtf((float)dh), rsq = 1.0f / sq;
+        const int q = t * 32 + l31;                               // this lane's query
+        float m = -INFINITY;
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt) {
+            st[kt] = tile_xyT<DHP>(Ks + kt * HT, Qs + t * HT, dsteps, l31, h);    // row = key, col = query
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float x = div_by(st[kt][r], sq, rsq) + Mk[kt * 32 + krow(r, h)];
+                st[kt][r] = x;
+                m = fmaxf(m, x);
+            }
+        }
+        AT_STAMP(4);
+        m = fmaxf(m, __shfl_xor(m, 32, 64));
+        if (m == -INFINITY) m = 0.f;
+        float sum = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float e = expf(st[kt][r] - m);
+                st[kt][r] = e;
+                sum += e;
+            }
+        sum += __shfl_xor(sum, 32, 64);
+        if (sum == 0.f) sum = 1.f;
+        const int64_t qrow = ((int64_t)n * H + hd) * S + q;
+        if (row_max && h == 0 && q < S) { row_max[qrow] = m; row_sum[qrow] = sum; }
+        const float scale = dc.p > 0.f ? 1.0f / (1.0f - dc.p) : 1.f;
+        uint64_t keep = ~0ull;
+        if (dc.p > 0.f) keep = keep_word64(dc, drop_threshold(dc.p), qrow, S, h);
+        const float rsum = 1.0f / sum;
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt) {
+            const uint32_t kw = (uint32_t)(keep >> (32 * kt));
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float p = div_by(st[kt][r], sum, rsum);
+                if (dc.p > 0.f) p = ((kw >> krow(r, h)) & 1u) ? p * scale : 0.f;
+                st[kt][r] = p;
+            }
+        }
+    }
+    AT_STAMP(5);
+    __syncthreads();                                           // all waves are done reading the Q tiles
+    AT_STAMP(6);
+    if (active) {
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) {
+            f32x16 o = zT_tile<DHP>(Vs, st[0], dt, l31, h);        // O^T[d][query], keys 0..31
+            zT_tile_acc<DHP>(o, Vs + HT, st[1], dt, l31, h);       // ... + keys 32..63
+            put_T<DHP>(Qs + t * HT, o, dt, l31, h);
+        }
+    }
+    AT_STAMP(7);
+    __syncthreads();
+    AT_STAMP(8);
+    heads_out<DHP, 64>(ctx + row0 * A + hd0 * dh, A, Qt, S, dh, nh, tid, vec, NTHR);
+    AT_STAMP(9); AT_STAMP_RT(10);
+}
+
+template <int DHP, int NHG>
+__global__ __launch_bounds__(128 * NHG) void mhsa_bwd_mfma2_kernel(const float* __restrict__ qkv, const int64_t* __restrict__ mask,
+                                                              const float* __restrict__ dctx, const float* __restrict__ row_max,
+                                                              const float* __restrict__ row_sum, float* __restrict__ dqkv,
+                                                              int S, int H, int dh, DropoutCfg dc, int vec) {
+    constexpr int LD = DHP + 1, TS = 64 * LD, HT = 32 * LD, NTHR = 128 * NHG;
+    constexpr int DT = DHP / 32;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* Qt = smem;
+    float* Kt = Qt + NHG * TS;
+    float* Vt = Kt + NHG * TS;
+    float* Gt = Vt + NHG * TS;
+    float* St = Gt + NHG * TS;          // [NHG][5][64]: max, sum, D, key-mask term, 1/sum ; then [NHG][64][2] keep words
+    const int tid = threadIdx.x, w = tid >> 6, hw = w >> 1, t = w & 1, lane = tid & 63, l31 = lane & 31, h = lane >> 5;
+    const int groups = (H + NHG - 1) / NHG;
+    const int n = blockIdx.x / groups, gidx = blockIdx.x - n * groups;
+    const int hd0 = gidx * NHG, nh = min(NHG, H - hd0), hd = hd0 + hw;
+    const bool active = hw < nh;
+    const int A = H * dh;
+    const int64_t ld = 3 * (int64_t)A;
+    const int64_t row0 = (int64_t)n * S;
+    const float* base = qkv + row0 * ld + hd0 * dh;
+    {
+        float* const tl[4] = {Qt, Kt, Vt, Gt};
+        const float* const gp[4] = {base, base + A, base + 2 * A, dctx + row0 * A + hd0 * dh};
+        const int64_t lds4[4] = {ld, ld, ld, (int64_t)A};
+        heads_in_n<DHP, 64, 4>(tl, gp, lds4, S, dh, nh, tid, vec, NTHR);
+    }
+    float* Qs = Qt + hw * TS; float* Ks = Kt + hw * TS; float* Vs = Vt + hw * TS; float* Gs = Gt + hw * TS;
+    float* Ms = St + hw * 320; float* Ls = Ms + 64; float* Dsh = Ms + 128; float* Mk = Ms + 192; float* Rl = Ms + 256;   // Rl = 1 / Ls
+    unsigned* Kb = reinterpret_cast<unsigned*>(St + NHG * 320) + hw * 128;     // [query][key tile]
+    const int64_t qrow0 = ((int64_t)n * H + hd) * S;
+    if (active) {
+        const bool ok = lane < S;
+        if (t == 0) {
+            tile_zero_pad<DHP, 64>(Qs, S, dh, lane); tile_zero_pad<DHP, 64>(Ks, S, dh, lane);
+            Ms[lane] = ok ? row_max[qrow0 + lane] : 0.f;
+            const float l = ok ? row_sum[qrow0 + lane] : 1.f;
+            Ls[lane] = l; Rl[lane] = 1.0f / l;
+        } else {
+            tile_zero_pad<DHP, 64>(Vs, S, dh, lane); tile_zero_pad<DHP, 64>(Gs, S, dh, lane);
+            Mk[lane] = ok ? (mask[(int64_t)n * S + lane] ? 0.f : dc.mask_fill) : -INFINITY;
+        }
+    }
+    __syncthreads();
+    const int dsteps = (dh + 7) >> 3;                     // groups of 4 k-steps
+    const float sq = sqrtf((float)dh), rsq = 1.0f / sq;
+    const float scale = dc.p > 0.f ? 1.0f / (1.0f - dc.p) : 1.0f;
+    f32x16 dq[DT], ds[2], pdn[2];
+    if (active) {
+        // ---------------- T orientation: row = key (both tiles), col = query (tile t; lane's query = t*32 + l31)
+        const int q = t * 32 + l31;
+        const float m = Ms[q], sum = Ls[q], rsum = Rl[q];
+        f32x16 st[2];
+        float pr[2][16];
+        float dpart = 0.f;
+        uint64_t keep = ~0ull;
+        if (dc.p > 0.f) {
+            keep = keep_word64(dc, drop_threshold(dc.p), qrow0 + q, S, h);
+            if (h == 0) { Kb[q * 2] = (uint32_t)keep; Kb[q * 2 + 1] = (uint32_t)(keep >> 32); }     // bit j = keep key kt*32 + j
+        }
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt) {
+            st[kt] = tile_xyT<DHP>(Ks + kt * HT, Qs + t * HT, dsteps, l31, h);
+            const f32x16 dpt = tile_xyT<DHP>(Vs + kt * HT, Gs + t * HT, dsteps, l31, h);   // dPd^T[key][query] = V[key].dO[query]
+            const uint32_t kw = (uint32_t)(keep >> (32 * kt));
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float x = div_by(st[kt][r], sq, rsq) + Mk[kt * 32 + krow(r, h)];
+                const float p = div_by(expf(x - m), sum, rsum);
+                const float pd = (dc.p > 0.f) ? (((kw >> krow(r, h)) & 1u) ? p * scale : 0.f) : p;
+                pr[kt][r] = p;
+                st[kt][r] = pd * dpt[r];                           // Pd * dPd
+                dpart += st[kt][r];
+            }
+        }
+        const float D = dpart + __shfl_xor(dpart, 32, 64);
+        if (h == 0) Dsh[q] = D;
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) st[kt][r] = div_by(st[kt][r] - pr[kt][r] * D, sq, rsq);      // dS^T
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) {                          // dQ^T[d][query], kept in registers
+            dq[dt] = zT_tile<DHP>(Ks, st[0], dt, l31, h);
+            zT_tile_acc<DHP>(dq[dt], Ks + HT, st[1], dt, l31, h);
+        }
+    }
+    __syncthreads();                                           // Dsh / Kb of BOTH query tiles visible
+    if (active) {
+        // ---------------- N orientation: row = query (both tiles), col = key (tile t; lane's key = t*32 + l31)
+        const float mk = Mk[t * 32 + l31];
+#pragma unroll
+        for (int qi = 0; qi < 2; ++qi) {
+            ds[qi] = tile_xyT<DHP>(Qs + qi * HT, Ks + t * HT, dsteps, l31, h);
+            const f32x16 dpn = tile_xyT<DHP>(Gs + qi * HT, Vs + t * HT, dsteps, l31, h);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int i = qi * 32 + krow(r, h);
+                const float x = div_by(ds[qi][r], sq, rsq) + mk;
+                const float p = div_by(expf(x - Ms[i]), Ls[i], Rl[i]);
+                float pd = p;
+                if (dc.p > 0.f) pd = ((Kb[i * 2 + t] >> l31) & 1u) ? p * scale : 0.f;
+                pdn[qi][r] = pd;
+                ds[qi][r] = div_by(pd * dpn[r] - p * Dsh[i], sq, rsq);       // dS[query][key]
+            }
+        }
+    }
+    __syncthreads();                                           // K and V tiles are dead: reuse them as staging
+    float* dbase = dqkv + row0 * ld + hd0 * dh;
+    if (active) {
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) {
+            put_T<DHP>(Ks + t * HT, dq[dt], dt, l31, h);
+            f32x16 o = zT_tile<DHP>(Qs, ds[0], dt, l31, h);        // dK^T[d][key]
+            zT_tile_acc<DHP>(o, Qs + HT, ds[1], dt, l31, h);
+            put_T<DHP>(Vs + t * HT, o, dt, l31, h);
+        }
+    }
+    __syncthreads();
+    heads_out<DHP, 64>(dbase, ld, Kt, S, dh, nh, tid, vec, NTHR);
+    heads_out<DHP, 64>(dbase + A, ld, Vt, S, dh, nh, tid, vec, NTHR);
+    __syncthreads();
+    if (active) {
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) {
+            f32x16 o = zT_tile<DHP>(Gs, pdn[0], dt, l31, h);       // dV^T[d][key]
+            zT_tile_acc<DHP>(o, Gs + HT, pdn[1], dt, l31, h);
+            put_T<DHP>(Ks + t * HT, o, dt, l31, h);
+        }
+    }
+    __syncthreads();
+    heads_out<DHP, 64>(dbase + 2 * A, ld, Kt, S, dh, nh, tid, vec, NTHR);
+}
+
 bool mhsa_mfma_supported(int S, int dh) { return S >= 1 && S <= 32 && dh >= 1 && dh <= 64; }
+bool mhsa_mfma2_supported(int S, int dh) { return S > 32 && S <= 64 && dh >= 1 && dh <= 64; }
 
 static bool vec_ok(const void* a, const void* b, int H, int dh, int hpg = HPG) {
     // 16-byte segments: 4 heads start on a 16-B boundary iff the row pitch and the q/k/v offsets do
@@ -446,10 +778,8 @@ static int launch_fwd(const T* qkv, const int64_t* mask, T* ctx, float* row_max,
     const int dhp = dh <= 32 ? 32 : 64;
     const int hpg = dhp == 32 ? 4 : 2;
     const dim3 grid((unsigned)(N * ((H + hpg - 1) / hpg)));
-    static const size_t lds_pad = getenv("NR_ATTN_LDS_PAD") ? (size_t)atoi(getenv("NR_ATTN_LDS_PAD")) : 0;      // occupancy experiment
-    const size_t lds = (size_t)3 * hpg * 32 * (dhp + 1) * sizeof(float) + lds_pad;
+    const size_t lds = ((size_t)3 * hpg * 32 * (dhp + 1) + 32) * sizeof(float);
     if (dhp == 32) {
-        if (lds_pad) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mhsa_fwd_mfma_kernel<32, T, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         hipLaunchKernelGGL((mhsa_fwd_mfma_kernel<32, T, 4>), grid, dim3(256), lds, s, qkv, mask, ctx, row_max, row_sum, S, H, dh, dc, vec);
     } else {
         static bool once = false;
@@ -464,7 +794,7 @@ static int launch_bwd(const T* qkv, const int64_t* mask, const T* dctx, const fl
     const int dhp = dh <= 32 ? 32 : 64;
     const int hpg = dhp == 32 ? 4 : 2;
     const dim3 grid((unsigned)(N * ((H + hpg - 1) / hpg)));
-    const size_t lds = ((size_t)4 * hpg * 32 * (dhp + 1) + hpg * 128 + hpg * 32) * sizeof(float);
+    const size_t lds = ((size_t)4 * hpg * 32 * (dhp + 1) + hpg * 160 + hpg * 32) * sizeof(float);
     if (dhp == 32) {
         static bool once = false;
         if (!once) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mhsa_bwd_mfma_kernel<32, T, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); once = true; }
@@ -479,12 +809,51 @@ static int launch_bwd(const T* qkv, const int64_t* mask, const T* dctx, const fl
 
 int mhsa_fwd_mfma(const float* qkv, const int64_t* mask, float* ctx, float* row_max, float* row_sum, int64_t N, int S, int H,
                   int dh, DropoutCfg dc, hipStream_t s) {
-    return launch_fwd<float>(qkv, mask, ctx, row_max, row_sum, N, S, H, dh, dc, vec_ok(qkv, ctx, H, dh, dh <= 32 ? 4 : 2) ? 1 : 0, s);
+    return launch_fwd<float>(qkv, mask, ctx, row_max, row_sum, N, S, H, dh, dc, vec_ok(qkv, ctx, H, dh, dh <= 32 ? 4 : 2) ? 4 : 0, s);
 }
 
 int mhsa_bwd_mfma(const float* qkv, const int64_t* mask, const float* dctx, const float* row_max, const float* row_sum,
                   float* dqkv, int64_t N, int S, int H, int dh, DropoutCfg dc, hipStream_t s) {
-    return launch_bwd<float>(qkv, mask, dctx, row_max, row_sum, dqkv, N, S, H, dh, dc, (vec_ok(qkv, dctx, H, dh, dh <= 32 ? 4 : 2) && vec_ok(dqkv, dqkv, H, dh, dh <= 32 ? 4 : 2)) ? 1 : 0, s);
+    return launch_bwd<float>(qkv, mask, dctx, row_max, row_sum, dqkv, N, S, H, dh, dc, (vec_ok(qkv, dctx, H, dh, dh <= 32 ? 4 : 2) && vec_ok(dqkv, dqkv, H, dh, dh <= 32 ? 4 : 2)) ? 4 : 0, s);
+}
+
+// 32 < S <= 64, f32 tensors, sequences not packed.  Two heads per workgroup at head dim <= 32, one above: a wave per SIMD
+// (the softmax / dropout phases are VALU-bound) and, for the 32-sequence user tower, 192 workgroups instead of 96.
+static int vec_width(const void* a, const void* b, int H, int dh, int hpg) {
+    const int A = H * dh;
+    const uintptr_t al = reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b);
+    if (A % 4 == 0 && (al & 15) == 0 && (hpg * dh) % 4 == 0 && (H % hpg == 0 || dh % 4 == 0)) return 4;
+    if (A % 2 == 0 && (al & 7) == 0 && (hpg * dh) % 2 == 0 && (H % hpg == 0 || dh % 2 == 0)) return 2;
+    return 0;
+}
+int mhsa_fwd_mfma2(const float* qkv, const int64_t* mask, float* ctx, float* row_max, float* row_sum, int64_t N, int S, int H,
+                   int dh, DropoutCfg dc, hipStream_t s) {
+    const int dhp = dh <= 32 ? 32 : 64;
+    const int hpg = dhp == 32 ? 2 : 1;
+    const int vec = vec_width(qkv, ctx, H, dh, hpg);
+    const dim3 grid((unsigned)(N * ((H + hpg - 1) / hpg)));
+    const size_t lds = ((size_t)3 * hpg * 64 * (dhp + 1) + 64) * sizeof(float);
+    if (dhp == 32) hipLaunchKernelGGL((mhsa_fwd_mfma2_kernel<32, 2>), grid, dim3(256), lds, s, qkv, mask, ctx, row_max, row_sum, S, H, dh, dc, vec);
+    else           hipLaunchKernelGGL((mhsa_fwd_mfma2_kernel<64, 1>), grid, dim3(128), lds, s, qkv, mask, ctx, row_max, row_sum, S, H, dh, dc, vec);
+    return check_launch("mhsa_fwd_mfma2");
+}
+
+int mhsa_bwd_mfma2(const float* qkv, const int64_t* mask, const float* dctx, const float* row_max, const float* row_sum,
+                   float* dqkv, int64_t N, int S, int H, int dh, DropoutCfg dc, hipStream_t s) {
+    const int dhp = dh <= 32 ? 32 : 64;
+    const int hpg = dhp == 32 ? 2 : 1;
+    const int vec = min(vec_width(qkv, dctx, H, dh, hpg), vec_width(dqkv, dqkv, H, dh, hpg));
+    const dim3 grid((unsigned)(N * ((H + hpg - 1) / hpg)));
+    const size_t lds = ((size_t)4 * hpg * 64 * (dhp + 1) + hpg * 320 + hpg * 128) * sizeof(float);
+    static bool once = false;
+    if (!once) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mhsa_bwd_mfma2_kernel<32, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mhsa_bwd_mfma2_kernel<64, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        once = true;
+    }
+    if (dhp == 32) hipLaunchKernelGGL((mhsa_bwd_mfma2_kernel<32, 2>), grid, dim3(256), lds, s, qkv, mask, dctx, row_max, row_sum, dqkv, S, H, dh, dc, vec);
+    else           hipLaunchKernelGGL((mhsa_bwd_mfma2_kernel<64, 1>), grid, dim3(128), lds, s, qkv, mask, dctx, row_max, row_sum, dqkv, S, H, dh, dc, vec);
+    return check_launch("mhsa_bwd_mfma2");
 }
 
 // bf16 tensors in HBM (raw 16-bit storage), f32 tiles and arithmetic; 16-byte pieces need A % 8 == 0 and aligned bases
@@ -508,3 +877,9 @@ int mhsa_bwd_mfma_h(const unsigned short* qkv, const int64_t* mask, const unsign
 }
 
 }  // namespace nr
+
+#ifdef NR_ATTN_STAMP
+extern "C" int nr_debug_attn_stamps(unsigned long long* host, int n) {
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(nr::attn_stamps), sizeof(unsigned long long) * n);
+}
+#endif

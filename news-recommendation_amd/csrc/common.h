@@ -57,6 +57,14 @@ __device__ __forceinline__ float wave_max(float v) {
     return v;
 }
 
+// a / b for many a and one b.  With rb = fl(1 / b) (correctly rounded), q = a * rb and one residual correction the result
+// is the correctly rounded quotient (Markstein), i.e. the same float as a / b, unless b's significand is all ones or the
+// quotient leaves the normal range; 3 instructions instead of the ~12 of an IEEE division.
+__device__ __forceinline__ float div_by(float a, float b, float rb) {
+    const float q = a * rb;
+    return fmaf(fmaf(-q, b, a), rb, q);
+}
+
 // exact erf GELU and its derivative (torch.nn.functional.gelu default)
 __device__ __forceinline__ float gelu_f(float z) { return 0.5f * z * (1.0f + erff(z * 0.70710678118654752440f)); }
 __device__ __forceinline__ float gelu_grad_f(float z) {
@@ -74,8 +82,11 @@ __device__ __forceinline__ Philox4 philox4x32_10(uint64_t seed, uint64_t idx, ui
     uint32_t c0 = (uint32_t)idx, c1 = (uint32_t)(idx >> 32), c2 = site, c3 = 0u;
 #pragma unroll
     for (int r = 0; r < 10; ++r) {
-        const uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
-        const uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+        // one full 32x32 -> 64 product per multiplier (v_mad_u64_u32) instead of a low and a high multiply:
+        // 32-bit integer multiplies issue at quarter rate and are most of this function's cycles
+        const uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
+        const uint32_t hi0 = (uint32_t)(p0 >> 32), lo0 = (uint32_t)p0;
+        const uint32_t hi1 = (uint32_t)(p1 >> 32), lo1 = (uint32_t)p1;
         const uint32_t n0 = hi1 ^ c1 ^ k0, n1 = lo1, n2 = hi0 ^ c3 ^ k1, n3 = lo0;
         c0 = n0; c1 = n1; c2 = n2; c3 = n3;
         k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;

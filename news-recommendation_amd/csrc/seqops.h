@@ -17,6 +17,12 @@ int mhsa_fwd_mfma(const float* qkv, const int64_t* mask, float* ctx, float* row_
                   int dh, DropoutCfg dc, hipStream_t s);
 int mhsa_bwd_mfma(const float* qkv, const int64_t* mask, const float* dctx, const float* row_max, const float* row_sum,
                   float* dqkv, int64_t N, int S, int H, int dh, DropoutCfg dc, hipStream_t s);
+// 32 < S <= 64 (two 32-row tiles per head, two waves per head); f32 tensors, sequences not packed
+bool mhsa_mfma2_supported(int S, int dh);
+int mhsa_fwd_mfma2(const float* qkv, const int64_t* mask, float* ctx, float* row_max, float* row_sum, int64_t N, int S, int H,
+                   int dh, DropoutCfg dc, hipStream_t s);
+int mhsa_bwd_mfma2(const float* qkv, const int64_t* mask, const float* dctx, const float* row_max, const float* row_sum,
+                   float* dqkv, int64_t N, int S, int H, int dh, DropoutCfg dc, hipStream_t s);
 
 // the same kernels over bf16 tensors in HBM (the bf16 build); tiles and arithmetic stay f32
 int mhsa_fwd_mfma_h(const unsigned short* qkv, const int64_t* mask, unsigned short* ctx, float* row_max, float* row_sum, int64_t N, int S,

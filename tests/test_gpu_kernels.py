@@ -285,7 +285,7 @@ def _mhsa_ref(qkv, mask, N, S, H, dh, keep, p):
     return torch.matmul(probs, v).permute(0, 2, 1, 3).reshape(N * S, A)
 
 
-@pytest.mark.parametrize("N,S,H,dh", [(1760, 32, 12, 25), (32, 50, 12, 25), (16, 50, 12, 64), (6, 9, 4, 6), (3, 64, 2, 32), (2, 1, 3, 5),
+@pytest.mark.parametrize("N,S,H,dh", [(1760, 32, 12, 25), (32, 50, 12, 25), (16, 50, 12, 64), (6, 9, 4, 6), (3, 64, 2, 32), (2, 1, 3, 5), (5, 33, 5, 25), (4, 40, 3, 40),
                                        (40, 96, 12, 25), (5, 128, 2, 32), (7, 65, 3, 7),    # title + abstract (-ef title abs): two waves per head
                                        (6, 96, 3, 64), (4, 120, 2, 64)])                    # ... at head dim 64: the backward recomputes P / dS (no room to stage them)
 @pytest.mark.parametrize("p", [0.0, 0.1])
