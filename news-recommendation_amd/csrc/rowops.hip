@@ -101,29 +101,87 @@ int gather_rows(const float* table, int64_t V, int E, const int64_t* ids, int64_
     return check_launch("gather_rows");
 }
 
-// grad_table[ids[r], :] += grad_rows[r, :]  (rows with id == padding_idx skipped:
-// nn.Embedding(padding_idx) semantics).  256 contiguous bytes per atomic wave-instruction.
-__global__ __launch_bounds__(256) void scatter_add_rows_kernel(const float* __restrict__ g, const int64_t* __restrict__ ids,
+// grad_table[ids[r], :] += grad_rows[r, :]  (rows with id == padding_idx skipped: nn.Embedding(padding_idx) semantics).
+// 256 contiguous bytes per atomic wave-instruction.  A few ids are in almost every title ([CLS], [SEP], frequent words) and
+// the atomics onto one table row serialise in L2 (measured: two such ids doubled the kernel's time), so a workgroup first
+// sums the rows of its 128-row window that share an id in LDS (up to SA_SLOTS distinct repeated ids per window; any
+// further ones go straight to the table, which is always correct) and sends one row of atomics per repeated id.
+constexpr int SA_WIN = 128;
+constexpr int SA_SLOTS = 8;
+constexpr int SA_NT = 1024;                       // 16 waves: 8 rows of the window each
+__global__ __launch_bounds__(SA_NT) void scatter_add_rows_kernel(const float* __restrict__ g, const int64_t* __restrict__ ids,
                                                                float* __restrict__ gt, int64_t n, int E, int64_t V,
                                                                int64_t padding_idx) {
-    const int lane = threadIdx.x & 63;
-    const int64_t wave = (int64_t)blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6);
-    const int64_t nwave = (int64_t)gridDim.x * WAVES_PER_BLOCK;
-    for (int64_t r = wave; r < n; r += nwave) {
-        const int64_t id = ids[r];
-        if (id == padding_idx || id < 0 || id >= V) continue;
-        const float* src = g + r * (int64_t)E;
-        float* dst = gt + id * (int64_t)E;
-        for (int c = lane; c < E; c += 64) atomicAdd(dst + c, src[c]);
+    extern __shared__ float sa_acc[];                 // [SA_SLOTS][E]
+    __shared__ int sid[SA_WIN];                       // id of the window's row, -1 = skipped
+    __shared__ int row_slot[SA_WIN];                  // LDS slot of the row's id, -1 = none (atomics go to the table)
+    __shared__ int slot_id[SA_SLOTS];
+    __shared__ int nslots;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int64_t nwin = (n + SA_WIN - 1) / SA_WIN;
+    for (int64_t w = blockIdx.x; w < nwin; w += gridDim.x) {
+        const int64_t r0 = w * SA_WIN;
+        const int cnt = (int)min((int64_t)SA_WIN, n - r0);
+        if (tid < SA_WIN) {
+            int v = -1;
+            if (tid < cnt) {
+                const int64_t id = ids[r0 + tid];
+                if (id != padding_idx && id >= 0 && id < V) v = (int)id;
+            }
+            sid[tid] = v;
+        }
+        if (tid == 0) nslots = 0;
+        for (int c = tid; c < SA_SLOTS * E; c += SA_NT) sa_acc[c] = 0.f;
+        __syncthreads();
+        // the first row of every repeated id claims a slot ...
+        int lead = -1;
+        if (tid < cnt && sid[tid] >= 0) {
+            const int my = sid[tid];
+            int dup = 0;
+            for (int j = cnt - 1; j >= 0; --j)
+                if (sid[j] == my) { lead = j; ++dup; }
+            int slot = -1;
+            if (lead == tid && dup > 1) {
+                slot = atomicAdd(&nslots, 1);
+                if (slot < SA_SLOTS) slot_id[slot] = my; else slot = -1;
+            }
+            if (lead == tid) row_slot[tid] = slot;
+        }
+        __syncthreads();
+        // ... and the other rows of that id follow it
+        if (lead >= 0 && lead != tid) row_slot[tid] = row_slot[lead];
+        __syncthreads();
+        for (int r = wv; r < cnt; r += SA_NT / 64) {
+            const int id = sid[r];
+            if (id < 0) continue;
+            const float* src = g + (r0 + r) * (int64_t)E;
+            const int slot = row_slot[r];
+            if (slot >= 0) {
+                float* dst = sa_acc + slot * E;
+                for (int c = lane; c < E; c += 64) atomicAdd(dst + c, src[c]);
+            } else {
+                float* dst = gt + (int64_t)id * E;
+                for (int c = lane; c < E; c += 64) atomicAdd(dst + c, src[c]);
+            }
+        }
+        __syncthreads();
+        const int ns = min(nslots, SA_SLOTS);
+        for (int c = tid; c < ns * E; c += SA_NT) {
+            const int sl = c / E;
+            atomicAdd(gt + (int64_t)slot_id[sl] * E + (c - sl * E), sa_acc[c]);
+        }
+        __syncthreads();
     }
 }
 
 int scatter_add_rows(const float* grad_rows, const int64_t* ids, int64_t n, int E, int64_t V, int64_t padding_idx,
                      float* grad_table, hipStream_t s) {
     if (n == 0) return NR_OK;
+    NR_UNSUPPORTED((size_t)SA_SLOTS * E * sizeof(float) > 60 * 1024, "scatter_add_rows: row width %d > %d", E, 60 * 1024 / 4 / SA_SLOTS);
     ProfScope prof(FAM_SCATTER, s, 2.0 * n * E * 4);
-    const int grid = (int)std::min<int64_t>(cdiv(n, WAVES_PER_BLOCK), 8192);
-    hipLaunchKernelGGL(scatter_add_rows_kernel, dim3(grid), dim3(256), 0, s, grad_rows, ids, grad_table, n, E, V, padding_idx);
+    const int grid = (int)std::min<int64_t>(cdiv(n, SA_WIN), 8192);
+    hipLaunchKernelGGL(scatter_add_rows_kernel, dim3(grid), dim3(SA_NT), (size_t)SA_SLOTS * E * sizeof(float), s, grad_rows, ids, grad_table, n,
+                       E, V, padding_idx);
     return check_launch("scatter_add_rows");
 }
 

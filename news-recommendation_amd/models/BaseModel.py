@@ -214,8 +214,8 @@ class TwoTowerBaseModel(BaseModel):
         ahead, self._ahead = getattr(self, "_ahead", None), None
         C, ids, masks, his_mask, keep, pending = ahead[1] if ahead is not None and ahead[0] is x else self._train_inputs(x)
         news = self._news_vectors(ids, masks, keep, pending)
-        cdd_news_embedding = news[:, :C]
-        user_embedding = self.userEncoder(news[:, C:], his_mask=his_mask)
+        cdd_news_embedding, his_news_embedding = ops.split_titles(news, C)
+        user_embedding = self.userEncoder(his_news_embedding, his_mask=his_mask)
         labels = x["label"].to(self.device)
         loss, _ = ops.score_cross_entropy(cdd_news_embedding, user_embedding, labels)
         return loss

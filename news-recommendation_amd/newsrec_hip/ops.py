@@ -748,10 +748,13 @@ class _ProjPool(torch.autograd.Function):
         ctx.save_for_backward(x, w, query, key, prob)
         ctx.plan, ctx.dims = plan, (nseq, S, D)
         ctx.mark_non_differentiable(prob)
+        ctx.set_materialize_grads(False)        # no zero tensor for the output nobody differentiates
         return out, prob
 
     @staticmethod
     def backward(ctx, g, _gprob):
+        if g is None:
+            return None, None, None, None, None, None
         x, w, query, key, prob = ctx.saved_tensors
         nseq, S, D = ctx.dims
         plan = ctx.plan
@@ -792,10 +795,13 @@ class _Pool(torch.autograd.Function):
                                           _p(prob), _stream()), "nr_query_pool_fwd_f32")
         ctx.save_for_backward(key, value, query, prob)
         ctx.mark_non_differentiable(prob)
+        ctx.set_materialize_grads(False)        # no zero tensor for the output nobody differentiates
         return out, prob
 
     @staticmethod
     def backward(ctx, g, _gprob):
+        if g is None:
+            return None, None, None, None
         key, value, query, prob = ctx.saved_tensors
         nseq, S, D = key.shape
         g = _f32(g, "grad")
@@ -891,6 +897,35 @@ def seq_reduce_from_table(table, idx, mean=False):
     return out
 
 
+# ----------------------------------------------------------------------------- candidate / history split
+class _SplitTitles(torch.autograd.Function):
+    """news [B, C+L, D] -> (candidates [B,C,D], history [B,L,D]), both contiguous.  Two slices would cost autograd two
+    zero-filled [B,C+L,D] buffers, two copies into them and an add; the backward here is one concatenation."""
+
+    @staticmethod
+    def forward(ctx, news, C):
+        ctx.C, ctx.shape = C, news.shape
+        ctx.set_materialize_grads(False)
+        return news[:, :C].contiguous(), news[:, C:].contiguous()
+
+    @staticmethod
+    def backward(ctx, g_cdd, g_his):
+        if g_cdd is None and g_his is None:
+            return None, None
+        B, n, D = ctx.shape
+        C = ctx.C
+        ref = g_cdd if g_cdd is not None else g_his
+        if g_cdd is None:
+            g_cdd = ref.new_zeros(B, C, D)
+        if g_his is None:
+            g_his = ref.new_zeros(B, n - C, D)
+        return torch.cat([g_cdd, g_his], dim=1), None
+
+
+def split_titles(news, C):
+    return _SplitTitles.apply(news, int(C))
+
+
 # ----------------------------------------------------------------------------- scoring (+ cross entropy)
 class _Score(torch.autograd.Function):
     @staticmethod
@@ -930,10 +965,13 @@ class _ScoreCE(torch.autograd.Function):
                                      _stream()), "nr_score_fwd_f32")
         ctx.save_for_backward(cdd, user, label, logits)
         ctx.mark_non_differentiable(logits)
+        ctx.set_materialize_grads(False)        # no zero tensor for the output nobody differentiates
         return loss, logits
 
     @staticmethod
     def backward(ctx, g, _gl):
+        if g is None:
+            return None, None, None
         cdd, user, label, logits = ctx.saved_tensors
         B, Cn, D = cdd.shape
         g = _f32(g, "grad").reshape(1)
