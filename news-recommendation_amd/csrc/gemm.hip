@@ -1392,6 +1392,8 @@ __global__ __launch_bounds__(XS_NT, 1) void gemm_x3s_kernel(const GemmParams p) 
     uint32_t* As = smem;
     uint32_t* Bs = smem + 3 * PL;
 
+    X3_STAMP(0);
+    X3_STAMP_RT(1);
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1483,9 +1485,13 @@ __global__ __launch_bounds__(XS_NT, 1) void gemm_x3s_kernel(const GemmParams p) 
     auto step = [&](auto set, auto next, int t) {
         gload(set, t + 3);
         compute();
+        if (t < 6) X3_STAMP(3 + 4 * t);
         __syncthreads();
+        if (t < 6) X3_STAMP(4 + 4 * t);
         if (t + 1 < nkt) lstore(next);
+        if (t < 6) X3_STAMP(5 + 4 * t);
         __syncthreads();
+        if (t < 6) X3_STAMP(6 + 4 * t);
     };
     if (nkt > 0) {
         gload(S0{}, 0);
@@ -1494,6 +1500,7 @@ __global__ __launch_bounds__(XS_NT, 1) void gemm_x3s_kernel(const GemmParams p) 
         lstore(S0{});
     }
     __syncthreads();
+    X3_STAMP(2);
     int t = 0;
     for (; t + 2 < nkt; t += 3) {
         step(S0{}, S1{}, t);
@@ -1503,6 +1510,7 @@ __global__ __launch_bounds__(XS_NT, 1) void gemm_x3s_kernel(const GemmParams p) 
     if (t < nkt) { step(S0{}, S1{}, t); ++t; }
     if (t < nkt) { step(S1{}, S2{}, t); ++t; }
 
+    X3_STAMP(28);
     float* fsm = reinterpret_cast<float*>(smem);
     if (do_csum) {
         // a column's k pairs are spread over the lanes' c and the four waves of its column half: shuffles, then one LDS
@@ -1567,6 +1575,8 @@ __global__ __launch_bounds__(XS_NT, 1) void gemm_x3s_kernel(const GemmParams p) 
     const int epi = partial ? EPI_NONE : p.epi;
     if (full) store_block_rt<1, 1, false>(out, Cout, mw, nw, l31, h, ub, epi, p);
     else      store_block_rt<1, 1, true>(out, Cout, mw, nw, l31, h, ub, epi, p);
+    X3_STAMP(29);
+    X3_STAMP_RT(30);
 }
 
 template <bool A_KC, bool B_KC>

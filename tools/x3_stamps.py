@@ -1,5 +1,5 @@
 """diagnostic (library built with -DNR_X3_EXP=4): where a workgroup of gemm_x3_kernel spends its cycles
-usage: python tools/x3_stamps.py R K N"""
+usage: python tools/x3_stamps.py R K N [BK]"""
 import ctypes, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "news-recommendation_amd"))
@@ -17,7 +17,8 @@ assert lib.nr_debug_x3_stamps(buf, n) == 0
 st = np.frombuffer(buf, dtype=np.uint64).reshape(8192, 32).astype(np.int64)
 nwg = int((st[:, 0] != 0).sum())
 st = st[:nwg]
-nkt = (K + 31) // 32
+BK = int(sys.argv[4]) if len(sys.argv) > 4 else 32          # 64: the small-tile kernel (gemm_x3s_kernel)
+nkt = (K + BK - 1) // BK
 t0 = st[:, 0]
 pro = st[:, 2] - t0
 nk = min(nkt, 6)
