@@ -37,15 +37,16 @@ constexpr int HPG = 4;                 // heads per workgroup
 __device__ __forceinline__ int krow(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
 __device__ __forceinline__ int fastdiv(int x, int inv20) { return (int)(((unsigned)x * (unsigned)inv20) >> 20); }   // x < 16384/d
 
-// zero what the MFMAs read but the copy does not write: rows >= S, and the columns dh .. dz-1 (the d loop runs in groups
-// of 4 steps = 8 columns, so dz = dh rounded up to 8)
-template <int DHP, int ROWS = 32>
+// LDS pitch of a head tile: dh rounded up to odd.  No pad columns: the d loops mask what lies past dh, so a 25-wide head
+// costs 25 floats per row, not 33 (3 backward / 4 forward workgroups per CU instead of 2 / 3 at dh = 25).
+__device__ __forceinline__ int tile_ld(int dh) { return dh | 1; }
+
+// zero what the MFMAs read but the copy does not write: rows >= S
+template <int ROWS = 32>
 __device__ __forceinline__ void tile_zero_pad(float* tile, int S, int dh, int lane) {
-    constexpr int LD = DHP + 1;
-    const int dz = ((dh + 7) >> 3) * 8;
-    if (lane < ROWS) for (int c = dh; c < dz; ++c) tile[lane * LD + c] = 0.f;
-    for (int idx = lane; idx < (ROWS - S) * dz; idx += 64) {
-        const int r = S + idx / dz, c = idx - (idx / dz) * dz;
+    const int LD = tile_ld(dh);
+    for (int idx = lane; idx < (ROWS - S) * dh; idx += 64) {
+        const int r = S + idx / dh, c = idx - (idx / dh) * dh;
         tile[r * LD + c] = 0.f;
     }
 }
@@ -55,7 +56,7 @@ __device__ __forceinline__ void tile_zero_pad(float* tile, int S, int dh, int la
 // arithmetic stay f32): 16-byte pieces of 8 elements when the segment allows it
 template <int DHP>
 __device__ __forceinline__ void heads_in(float* tiles, const unsigned short* __restrict__ g, int64_t ld, int S, int dh, int nh, int tid, bool vec, int nthr = 256) {
-    constexpr int LD = DHP + 1, TS = 32 * LD;
+    const int LD = tile_ld(dh), TS = 32 * LD;
     const int W = nh * dh;
     const int inv_dh = (1048576 + dh - 1) / dh;
     if (vec && (W & 7) == 0) {
@@ -88,7 +89,7 @@ template <int DHP, int ROWS, int NSRC, int VW>
 __device__ __forceinline__ void heads_in_vec(float* const (&tiles)[NSRC], const float* const (&g)[NSRC], const int64_t (&ld)[NSRC],
                                              int S, int dh, int nh, int tid, int nthr) {
     typedef float vt __attribute__((ext_vector_type(VW)));
-    constexpr int LD = DHP + 1, TS = ROWS * LD;
+    const int LD = tile_ld(dh), TS = ROWS * LD;
     const int inv_dh = (1048576 + dh - 1) / dh;
     const int nq = (nh * dh) / VW;
     const int inv_nq = (1048576 + nq - 1) / nq;
@@ -117,7 +118,7 @@ __device__ __forceinline__ void heads_in_n(float* const (&tiles)[NSRC], const fl
     if (vec == 4) heads_in_vec<DHP, ROWS, NSRC, 4>(tiles, g, ld, S, dh, nh, tid, nthr);
     else if (vec == 2) heads_in_vec<DHP, ROWS, NSRC, 2>(tiles, g, ld, S, dh, nh, tid, nthr);
     else {
-        constexpr int LD = DHP + 1, TS = ROWS * LD;
+        const int LD = tile_ld(dh), TS = ROWS * LD;
         const int W = nh * dh;
         const int inv_dh = (1048576 + dh - 1) / dh;
         for (int idx = tid; idx < S * W; idx += nthr) {
@@ -148,7 +149,7 @@ __device__ __forceinline__ uint32_t apack2(float lo, float hi) {
 }
 template <int DHP>
 __device__ __forceinline__ void heads_out(unsigned short* __restrict__ g, int64_t ld, const float* tiles, int S, int dh, int nh, int tid, int vec, int nthr = 256) {
-    constexpr int LD = DHP + 1, TS = 32 * LD;
+    const int LD = tile_ld(dh), TS = 32 * LD;
     const int W = nh * dh;
     const int inv_dh = (1048576 + dh - 1) / dh;
     if (vec && (W & 7) == 0) {
@@ -178,7 +179,7 @@ __device__ __forceinline__ void heads_out(unsigned short* __restrict__ g, int64_
 template <int DHP, int ROWS, int VW>
 __device__ __forceinline__ void heads_out_vec(float* __restrict__ g, int64_t ld, const float* tiles, int S, int dh, int nh, int tid, int nthr) {
     typedef float vt __attribute__((ext_vector_type(VW)));
-    constexpr int LD = DHP + 1, TS = ROWS * LD;
+    const int LD = tile_ld(dh), TS = ROWS * LD;
     const int inv_dh = (1048576 + dh - 1) / dh;
     const int nq = (nh * dh) / VW;
     const int inv_nq = (1048576 + nq - 1) / nq;
@@ -200,7 +201,7 @@ __device__ __forceinline__ void heads_out(float* __restrict__ g, int64_t ld, con
     if (vec == 4) heads_out_vec<DHP, ROWS, 4>(g, ld, tiles, S, dh, nh, tid, nthr);
     else if (vec == 2) heads_out_vec<DHP, ROWS, 2>(g, ld, tiles, S, dh, nh, tid, nthr);
     else {
-        constexpr int LD = DHP + 1, TS = ROWS * LD;
+        const int LD = tile_ld(dh), TS = ROWS * LD;
         const int W = nh * dh;
         const int inv_dh = (1048576 + dh - 1) / dh;
         for (int idx = tid; idx < S * W; idx += nthr) {
@@ -213,30 +214,41 @@ __device__ __forceinline__ void heads_out(float* __restrict__ g, int64_t ld, con
 }
 
 // acc[r] = sum_d X[row(r,h)][d] * Y[l31][d]  i.e. tile = X . Y^T with row = X's row, col = Y's row.  The d loop runs in
-// groups of 4 k-steps (8 columns, zero-padded by tile_zero_pad): the 8 LDS reads of a group are issued together, so the
-// MFMA chain does not wait one LDS round trip per step.
-template <int DHP>
-__device__ __forceinline__ f32x16 tile_xyT(const float* Xs, const float* Ys, int dgroups, int l31, int h) {
-    constexpr int LD = DHP + 1;
+// groups of 4 k-steps (8 columns): the 8 LDS reads of a group are issued together, so the MFMA chain does not wait one LDS
+// round trip per step.  The last group masks the columns past dh and skips the k-steps that lie wholly past it.
+__device__ __forceinline__ f32x16 tile_xyT(const float* Xs, const float* Ys, int dh, int l31, int h) {
+    const int LD = tile_ld(dh);
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
     const float* xp = Xs + l31 * LD + h;
     const float* yp = Ys + l31 * LD + h;
-    for (int g = 0; g < dgroups; ++g) {
+    const int last = (dh - 1) >> 3;                        // the group that holds column dh-1
+    for (int g = 0; g < last; ++g) {
         float a[4], b[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) { a[u] = xp[8 * g + 2 * u]; b[u] = yp[8 * g + 2 * u]; }
 #pragma unroll
         for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u], b[u], acc, 0, 0, 0);
     }
+    {
+        float a[4], b[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const bool ok = 8 * last + 2 * u + h < dh;
+            a[u] = ok ? xp[8 * last + 2 * u] : 0.f;
+            b[u] = ok ? yp[8 * last + 2 * u] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (8 * last + 2 * u < dh) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u], b[u], acc, 0, 0, 0);     // uniform
+    }
     return acc;
 }
 
-// out[r] = sum over the tile's ROW index k of Z[k][dt*32 + row(r,h)] * tile[k][l31]   (Z^T . tile)
-template <int DHP>
-__device__ __forceinline__ f32x16 zT_tile(const float* Zs, const f32x16& tile, int dt, int l31, int h) {
-    constexpr int LD = DHP + 1;
+// out[r] = sum over the tile's ROW index k of Z[k][dt*32 + row(r,h)] * tile[k][l31]   (Z^T . tile).  Feature rows past dh
+// read whatever follows in LDS: they only reach result rows past dh, which put_T does not store.
+__device__ __forceinline__ f32x16 zT_tile(const float* Zs, const f32x16& tile, int dt, int l31, int h, int LD) {
     f32x16 o;
 #pragma unroll
     for (int r = 0; r < 16; ++r) o[r] = 0.f;
@@ -249,9 +261,7 @@ __device__ __forceinline__ f32x16 zT_tile(const float* Zs, const f32x16& tile, i
 }
 
 // the same, added to o (a second 32-row tile of the summed index)
-template <int DHP>
-__device__ __forceinline__ void zT_tile_acc(f32x16& o, const float* Zs, const f32x16& tile, int dt, int l31, int h) {
-    constexpr int LD = DHP + 1;
+__device__ __forceinline__ void zT_tile_acc(f32x16& o, const float* Zs, const f32x16& tile, int dt, int l31, int h, int LD) {
 #pragma unroll
     for (int s = 0; s < 16; ++s) {
         const float a = Zs[krow(s, h) * LD + dt * 32 + l31];
@@ -259,12 +269,13 @@ __device__ __forceinline__ void zT_tile_acc(f32x16& o, const float* Zs, const f3
     }
 }
 
-// result tile rows = feature d (dt*32 + row(r,h)), col = sequence position l31 -> LDS [pos][d]
-template <int DHP>
-__device__ __forceinline__ void put_T(float* Ts, const f32x16& o, int dt, int l31, int h) {
-    constexpr int LD = DHP + 1;
+// result tile rows = feature d (dt*32 + row(r,h)), col = sequence position l31 -> LDS [pos][d], features < dh only
+__device__ __forceinline__ void put_T(float* Ts, const f32x16& o, int dt, int l31, int h, int LD, int dh) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) Ts[l31 * LD + dt * 32 + krow(r, h)] = o[r];
+    for (int r = 0; r < 16; ++r) {
+        const int d = dt * 32 + krow(r, h);
+        if (d < dh) Ts[l31 * LD + d] = o[r];
+    }
 }
 
 // keep flags (bit r = keep element krow(r,h)) of query row `qrow` for this lane's 16 keys
@@ -317,7 +328,7 @@ __global__ __launch_bounds__(64 * NHG) void mhsa_fwd_mfma_kernel(const T* __rest
                                                             T* __restrict__ ctx, float* __restrict__ row_max,
                                                             float* __restrict__ row_sum, int S, int H, int dh, DropoutCfg dc,
                                                             int vec) {
-    constexpr int LD = DHP + 1, TS = 32 * LD;
+    const int LD = tile_ld(dh), TS = 32 * LD;
     constexpr int DT = DHP / 32;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* Qt = smem;                  // [NHG][TS]  (reused for the output tiles)
@@ -345,13 +356,12 @@ __global__ __launch_bounds__(64 * NHG) void mhsa_fwd_mfma_kernel(const T* __rest
         heads_in_n<DHP, 32, 3>(tl, gp, lds3, Sn, dh, nh, tid, vec, 64 * NHG);
     }
     float* Qs = Qt + w * TS; float* Ks = Kt + w * TS; float* Vs = Vt + w * TS;
-    if (active) { tile_zero_pad<DHP>(Qs, Sn, dh, lane); tile_zero_pad<DHP>(Ks, Sn, dh, lane); tile_zero_pad<DHP>(Vs, Sn, dh, lane); }
+    if (active) { tile_zero_pad<32>(Qs, Sn, dh, lane); tile_zero_pad<32>(Ks, Sn, dh, lane); tile_zero_pad<32>(Vs, Sn, dh, lane); }
     __syncthreads();
     f32x16 st;
     if (active) {
-        const int dsteps = (dh + 7) >> 3;                     // groups of 4 k-steps
-        const float sq = sqrtf((float)dh), rsq = 1.0f / sq;
-        st = tile_xyT<DHP>(Ks, Qs, dsteps, l31, h);           // row = key, col = query (this lane's query = l31)
+                const float sq = sqrtf((float)dh), rsq = 1.0f / sq;
+        st = tile_xyT(Ks, Qs, dh, l31, h);           // row = key, col = query (this lane's query = l31)
         float m = -INFINITY;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -387,8 +397,8 @@ __global__ __launch_bounds__(64 * NHG) void mhsa_fwd_mfma_kernel(const T* __rest
     if (active) {
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt) {
-            const f32x16 o = zT_tile<DHP>(Vs, st, dt, l31, h);     // O^T[d][query]
-            put_T<DHP>(Qs, o, dt, l31, h);
+            const f32x16 o = zT_tile(Vs, st, dt, l31, h, LD);     // O^T[d][query]
+            put_T(Qs, o, dt, l31, h, LD, dh);
         }
     }
     __syncthreads();
@@ -400,14 +410,14 @@ __global__ __launch_bounds__(64 * NHG) void mhsa_bwd_mfma_kernel(const T* __rest
                                                             const T* __restrict__ dctx, const float* __restrict__ row_max,
                                                             const float* __restrict__ row_sum, T* __restrict__ dqkv,
                                                             int S, int H, int dh, DropoutCfg dc, int vec) {
-    constexpr int LD = DHP + 1, TS = 32 * LD;
+    const int LD = tile_ld(dh), TS = 32 * LD;
     constexpr int DT = DHP / 32;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* Qt = smem;
     float* Kt = Qt + NHG * TS;
     float* Vt = Kt + NHG * TS;
     float* Gt = Vt + NHG * TS;
-    float* St = Gt + NHG * TS;          // [NHG][5][32]: max, sum, D, key-mask term, 1/sum ; then [NHG][32] keep words
+    float* St = Gt + NHG * TS;          // [NHG][4][32]: max, 1/sum, D, key-mask term ; then [NHG][32] keep words
     const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63, l31 = lane & 31, h = lane >> 5;
     const int groups = (H + NHG - 1) / NHG;
     const int n = blockIdx.x / groups, gidx = blockIdx.x - n * groups;
@@ -426,30 +436,30 @@ __global__ __launch_bounds__(64 * NHG) void mhsa_bwd_mfma_kernel(const T* __rest
         heads_in_n<DHP, 32, 4>(tl, gp, lds4, Sn, dh, nh, tid, vec, 64 * NHG);
     }
     float* Qs = Qt + w * TS; float* Ks = Kt + w * TS; float* Vs = Vt + w * TS; float* Gs = Gt + w * TS;
-    float* Ms = St + w * 160; float* Ls = Ms + 32; float* Dsh = Ms + 64; float* Mk = Ms + 96; float* Rl = Ms + 128;   // Rl = 1 / Ls
-    unsigned* Kb = reinterpret_cast<unsigned*>(St + NHG * 160) + w * 32;
+    // Rl = 1 / row_sum: the backward forms p = exp(x - max) * Rl (within an ulp of the forward's quotient; one array and
+    // two instructions per element less — with the dh-wide tiles this is what lets three workgroups share a CU at dh = 25)
+    float* Ms = St + w * 128; float* Rl = Ms + 32; float* Dsh = Ms + 64; float* Mk = Ms + 96;
+    unsigned* Kb = reinterpret_cast<unsigned*>(St + NHG * 128) + w * 32;
     const int64_t qrow0 = ((int64_t)n * H + hd) * S;
     if (active) {
-        tile_zero_pad<DHP>(Qs, Sn, dh, lane); tile_zero_pad<DHP>(Ks, Sn, dh, lane);
-        tile_zero_pad<DHP>(Vs, Sn, dh, lane); tile_zero_pad<DHP>(Gs, Sn, dh, lane);
+        tile_zero_pad<32>(Qs, Sn, dh, lane); tile_zero_pad<32>(Ks, Sn, dh, lane);
+        tile_zero_pad<32>(Vs, Sn, dh, lane); tile_zero_pad<32>(Gs, Sn, dh, lane);
         if (lane < 32) {
             const bool ok = lane < Sn;
             Ms[lane] = ok ? row_max[qrow0 + lane] : 0.f;
-            const float l = ok ? row_sum[qrow0 + lane] : 1.f;
-            Ls[lane] = l; Rl[lane] = 1.0f / l;
+            Rl[lane] = ok ? 1.0f / row_sum[qrow0 + lane] : 1.f;
             Mk[lane] = ok ? (mask[(int64_t)n * S + lane] ? 0.f : dc.mask_fill) : -INFINITY;
         }
     }
     __syncthreads();
-    const int dsteps = (dh + 7) >> 3;                     // groups of 4 k-steps
-    const float sq = sqrtf((float)dh), rsq = 1.0f / sq;
+        const float sq = sqrtf((float)dh), rsq = 1.0f / sq;
     const float scale = dc.p > 0.f ? 1.0f / (1.0f - dc.p) : 1.0f;
     f32x16 dq[DT], ds, pdn;
     if (active) {
         // ---------------- T orientation: row = key, col = query (lane's query = l31)
-        f32x16 st = tile_xyT<DHP>(Ks, Qs, dsteps, l31, h);
-        const f32x16 dpt = tile_xyT<DHP>(Vs, Gs, dsteps, l31, h);   // dPd^T[key][query] = V[key].dO[query]
-        const float m = Ms[l31], sum = Ls[l31], rsum = Rl[l31];
+        f32x16 st = tile_xyT(Ks, Qs, dh, l31, h);
+        const f32x16 dpt = tile_xyT(Vs, Gs, dh, l31, h);   // dPd^T[key][query] = V[key].dO[query]
+        const float m = Ms[l31], rsum = Rl[l31];
         unsigned bits = 0xFFFFu;
         if (dc.p > 0.f) {
             bits = keep_bits16(dc, drop_threshold(dc.p), qrow0 + l31, S, h);
@@ -465,7 +475,7 @@ __global__ __launch_bounds__(64 * NHG) void mhsa_bwd_mfma_kernel(const T* __rest
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const float x = div_by(st[r], sq, rsq) + Mk[krow(r, h)];
-            const float p = div_by(expf(x - m), sum, rsum);
+            const float p = expf(x - m) * rsum;
             const float pd = (dc.p > 0.f) ? (((bits >> r) & 1u) ? p * scale : 0.f) : p;
             pr[r] = p;
             st[r] = pd * dpt[r];                               // Pd * dPd
@@ -476,19 +486,19 @@ __global__ __launch_bounds__(64 * NHG) void mhsa_bwd_mfma_kernel(const T* __rest
 #pragma unroll
         for (int r = 0; r < 16; ++r) st[r] = div_by(st[r] - pr[r] * D, sq, rsq);      // dS^T
 #pragma unroll
-        for (int dt = 0; dt < DT; ++dt) dq[dt] = zT_tile<DHP>(Ks, st, dt, l31, h);   // dQ^T[d][query], kept in registers
+        for (int dt = 0; dt < DT; ++dt) dq[dt] = zT_tile(Ks, st, dt, l31, h, LD);   // dQ^T[d][query], kept in registers
     }
     __syncthreads();                                           // Dsh / Kb visible (same wave, but keep it simple)
     if (active) {
         // ---------------- N orientation: row = query, col = key (lane's key = l31)
-        ds = tile_xyT<DHP>(Qs, Ks, dsteps, l31, h);
-        const f32x16 dpn = tile_xyT<DHP>(Gs, Vs, dsteps, l31, h);
+        ds = tile_xyT(Qs, Ks, dh, l31, h);
+        const f32x16 dpn = tile_xyT(Gs, Vs, dh, l31, h);
         const float mk = Mk[l31];
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int i = krow(r, h);
             const float x = div_by(ds[r], sq, rsq) + mk;
-            const float p = div_by(expf(x - Ms[i]), Ls[i], Rl[i]);
+            const float p = expf(x - Ms[i]) * Rl[i];
             float pd = p;
             if (dc.p > 0.f) pd = ((Kb[i] >> l31) & 1u) ? p * scale : 0.f;
             pdn[r] = pd;
@@ -500,9 +510,9 @@ __global__ __launch_bounds__(64 * NHG) void mhsa_bwd_mfma_kernel(const T* __rest
     if (active) {
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt) {
-            put_T<DHP>(Ks, dq[dt], dt, l31, h);
-            const f32x16 o = zT_tile<DHP>(Qs, ds, dt, l31, h);     // dK^T[d][key]
-            put_T<DHP>(Vs, o, dt, l31, h);
+            put_T(Ks, dq[dt], dt, l31, h, LD, dh);
+            const f32x16 o = zT_tile(Qs, ds, dt, l31, h, LD);     // dK^T[d][key]
+            put_T(Vs, o, dt, l31, h, LD, dh);
         }
     }
     __syncthreads();
@@ -512,8 +522,8 @@ __global__ __launch_bounds__(64 * NHG) void mhsa_bwd_mfma_kernel(const T* __rest
     if (active) {
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt) {
-            const f32x16 o = zT_tile<DHP>(Gs, pdn, dt, l31, h);    // dV^T[d][key]
-            put_T<DHP>(Ks, o, dt, l31, h);
+            const f32x16 o = zT_tile(Gs, pdn, dt, l31, h, LD);    // dV^T[d][key]
+            put_T(Ks, o, dt, l31, h, LD, dh);
         }
     }
     __syncthreads();
@@ -530,7 +540,8 @@ __global__ __launch_bounds__(128 * NHG) void mhsa_fwd_mfma2_kernel(const float* 
                                                               float* __restrict__ ctx, float* __restrict__ row_max,
                                                               float* __restrict__ row_sum, int S, int H, int dh, DropoutCfg dc,
                                                               int vec) {
-    constexpr int LD = DHP + 1, TS = 64 * LD, HT = 32 * LD, NTHR = 128 * NHG;
+    const int LD = tile_ld(dh), TS = 64 * LD, HT = 32 * LD;
+    constexpr int NTHR = 128 * NHG;
     constexpr int DT = DHP / 32;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* Qt = smem;                  // [NHG][TS]  (reused for the output tiles)
@@ -556,21 +567,20 @@ __global__ __launch_bounds__(128 * NHG) void mhsa_fwd_mfma2_kernel(const float* 
     }
     float* Qs = Qt + hw * TS; float* Ks = Kt + hw * TS; float* Vs = Vt + hw * TS;
     if (active) {
-        if (t == 0) { tile_zero_pad<DHP, 64>(Qs, S, dh, lane); tile_zero_pad<DHP, 64>(Ks, S, dh, lane); }
-        else tile_zero_pad<DHP, 64>(Vs, S, dh, lane);
+        if (t == 0) { tile_zero_pad<64>(Qs, S, dh, lane); tile_zero_pad<64>(Ks, S, dh, lane); }
+        else tile_zero_pad<64>(Vs, S, dh, lane);
     }
     AT_STAMP(2);
     __syncthreads();
     AT_STAMP(3);
     f32x16 st[2];
     if (active) {
-        const int dsteps = (dh + 7) >> 3;                     // groups of 4 k-steps
-        const float sq = sqrtf((float)dh), rsq = 1.0f / sq;
+                const float sq = sqrtf((float)dh), rsq = 1.0f / sq;
         const int q = t * 32 + l31;                               // this lane's query
         float m = -INFINITY;
 #pragma unroll
         for (int kt = 0; kt < 2; ++kt) {
-            st[kt] = tile_xyT<DHP>(Ks + kt * HT, Qs + t * HT, dsteps, l31, h);    // row = key, col = query
+            st[kt] = tile_xyT(Ks + kt * HT, Qs + t * HT, dh, l31, h);    // row = key, col = query
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const float x = div_by(st[kt][r], sq, rsq) + Mk[kt * 32 + krow(r, h)];
@@ -615,9 +625,9 @@ __global__ __launch_bounds__(128 * NHG) void mhsa_fwd_mfma2_kernel(const float* 
     if (active) {
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt) {
-            f32x16 o = zT_tile<DHP>(Vs, st[0], dt, l31, h);        // O^T[d][query], keys 0..31
-            zT_tile_acc<DHP>(o, Vs + HT, st[1], dt, l31, h);       // ... + keys 32..63
-            put_T<DHP>(Qs + t * HT, o, dt, l31, h);
+            f32x16 o = zT_tile(Vs, st[0], dt, l31, h, LD);        // O^T[d][query], keys 0..31
+            zT_tile_acc(o, Vs + HT, st[1], dt, l31, h, LD);       // ... + keys 32..63
+            put_T(Qs + t * HT, o, dt, l31, h, LD, dh);
         }
     }
     AT_STAMP(7);
@@ -632,14 +642,15 @@ __global__ __launch_bounds__(128 * NHG) void mhsa_bwd_mfma2_kernel(const float* 
                                                               const float* __restrict__ dctx, const float* __restrict__ row_max,
                                                               const float* __restrict__ row_sum, float* __restrict__ dqkv,
                                                               int S, int H, int dh, DropoutCfg dc, int vec) {
-    constexpr int LD = DHP + 1, TS = 64 * LD, HT = 32 * LD, NTHR = 128 * NHG;
+    const int LD = tile_ld(dh), TS = 64 * LD, HT = 32 * LD;
+    constexpr int NTHR = 128 * NHG;
     constexpr int DT = DHP / 32;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* Qt = smem;
     float* Kt = Qt + NHG * TS;
     float* Vt = Kt + NHG * TS;
     float* Gt = Vt + NHG * TS;
-    float* St = Gt + NHG * TS;          // [NHG][5][64]: max, sum, D, key-mask term, 1/sum ; then [NHG][64][2] keep words
+    float* St = Gt + NHG * TS;          // [NHG][4][64]: max, 1/sum, D, key-mask term ; then [NHG][64][2] keep words
     const int tid = threadIdx.x, w = tid >> 6, hw = w >> 1, t = w & 1, lane = tid & 63, l31 = lane & 31, h = lane >> 5;
     const int groups = (H + NHG - 1) / NHG;
     const int n = blockIdx.x / groups, gidx = blockIdx.x - n * groups;
@@ -656,30 +667,28 @@ __global__ __launch_bounds__(128 * NHG) void mhsa_bwd_mfma2_kernel(const float* 
         heads_in_n<DHP, 64, 4>(tl, gp, lds4, S, dh, nh, tid, vec, NTHR);
     }
     float* Qs = Qt + hw * TS; float* Ks = Kt + hw * TS; float* Vs = Vt + hw * TS; float* Gs = Gt + hw * TS;
-    float* Ms = St + hw * 320; float* Ls = Ms + 64; float* Dsh = Ms + 128; float* Mk = Ms + 192; float* Rl = Ms + 256;   // Rl = 1 / Ls
-    unsigned* Kb = reinterpret_cast<unsigned*>(St + NHG * 320) + hw * 128;     // [query][key tile]
+    float* Ms = St + hw * 256; float* Rl = Ms + 64; float* Dsh = Ms + 128; float* Mk = Ms + 192;      // Rl = 1 / row_sum
+    unsigned* Kb = reinterpret_cast<unsigned*>(St + NHG * 256) + hw * 128;     // [query][key tile]
     const int64_t qrow0 = ((int64_t)n * H + hd) * S;
     if (active) {
         const bool ok = lane < S;
         if (t == 0) {
-            tile_zero_pad<DHP, 64>(Qs, S, dh, lane); tile_zero_pad<DHP, 64>(Ks, S, dh, lane);
+            tile_zero_pad<64>(Qs, S, dh, lane); tile_zero_pad<64>(Ks, S, dh, lane);
             Ms[lane] = ok ? row_max[qrow0 + lane] : 0.f;
-            const float l = ok ? row_sum[qrow0 + lane] : 1.f;
-            Ls[lane] = l; Rl[lane] = 1.0f / l;
+            Rl[lane] = ok ? 1.0f / row_sum[qrow0 + lane] : 1.f;
         } else {
-            tile_zero_pad<DHP, 64>(Vs, S, dh, lane); tile_zero_pad<DHP, 64>(Gs, S, dh, lane);
+            tile_zero_pad<64>(Vs, S, dh, lane); tile_zero_pad<64>(Gs, S, dh, lane);
             Mk[lane] = ok ? (mask[(int64_t)n * S + lane] ? 0.f : dc.mask_fill) : -INFINITY;
         }
     }
     __syncthreads();
-    const int dsteps = (dh + 7) >> 3;                     // groups of 4 k-steps
-    const float sq = sqrtf((float)dh), rsq = 1.0f / sq;
+        const float sq = sqrtf((float)dh), rsq = 1.0f / sq;
     const float scale = dc.p > 0.f ? 1.0f / (1.0f - dc.p) : 1.0f;
     f32x16 dq[DT], ds[2], pdn[2];
     if (active) {
         // ---------------- T orientation: row = key (both tiles), col = query (tile t; lane's query = t*32 + l31)
         const int q = t * 32 + l31;
-        const float m = Ms[q], sum = Ls[q], rsum = Rl[q];
+        const float m = Ms[q], rsum = Rl[q];
         f32x16 st[2];
         float pr[2][16];
         float dpart = 0.f;
@@ -690,13 +699,13 @@ __global__ __launch_bounds__(128 * NHG) void mhsa_bwd_mfma2_kernel(const float* 
         }
 #pragma unroll
         for (int kt = 0; kt < 2; ++kt) {
-            st[kt] = tile_xyT<DHP>(Ks + kt * HT, Qs + t * HT, dsteps, l31, h);
-            const f32x16 dpt = tile_xyT<DHP>(Vs + kt * HT, Gs + t * HT, dsteps, l31, h);   // dPd^T[key][query] = V[key].dO[query]
+            st[kt] = tile_xyT(Ks + kt * HT, Qs + t * HT, dh, l31, h);
+            const f32x16 dpt = tile_xyT(Vs + kt * HT, Gs + t * HT, dh, l31, h);   // dPd^T[key][query] = V[key].dO[query]
             const uint32_t kw = (uint32_t)(keep >> (32 * kt));
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const float x = div_by(st[kt][r], sq, rsq) + Mk[kt * 32 + krow(r, h)];
-                const float p = div_by(expf(x - m), sum, rsum);
+                const float p = expf(x - m) * rsum;
                 const float pd = (dc.p > 0.f) ? (((kw >> krow(r, h)) & 1u) ? p * scale : 0.f) : p;
                 pr[kt][r] = p;
                 st[kt][r] = pd * dpt[r];                           // Pd * dPd
@@ -711,8 +720,8 @@ __global__ __launch_bounds__(128 * NHG) void mhsa_bwd_mfma2_kernel(const float* 
             for (int r = 0; r < 16; ++r) st[kt][r] = div_by(st[kt][r] - pr[kt][r] * D, sq, rsq);      // dS^T
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt) {                          // dQ^T[d][query], kept in registers
-            dq[dt] = zT_tile<DHP>(Ks, st[0], dt, l31, h);
-            zT_tile_acc<DHP>(dq[dt], Ks + HT, st[1], dt, l31, h);
+            dq[dt] = zT_tile(Ks, st[0], dt, l31, h, LD);
+            zT_tile_acc(dq[dt], Ks + HT, st[1], dt, l31, h, LD);
         }
     }
     __syncthreads();                                           // Dsh / Kb of BOTH query tiles visible
@@ -721,13 +730,13 @@ __global__ __launch_bounds__(128 * NHG) void mhsa_bwd_mfma2_kernel(const float* 
         const float mk = Mk[t * 32 + l31];
 #pragma unroll
         for (int qi = 0; qi < 2; ++qi) {
-            ds[qi] = tile_xyT<DHP>(Qs + qi * HT, Ks + t * HT, dsteps, l31, h);
-            const f32x16 dpn = tile_xyT<DHP>(Gs + qi * HT, Vs + t * HT, dsteps, l31, h);
+            ds[qi] = tile_xyT(Qs + qi * HT, Ks + t * HT, dh, l31, h);
+            const f32x16 dpn = tile_xyT(Gs + qi * HT, Vs + t * HT, dh, l31, h);
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int i = qi * 32 + krow(r, h);
                 const float x = div_by(ds[qi][r], sq, rsq) + mk;
-                const float p = div_by(expf(x - Ms[i]), Ls[i], Rl[i]);
+                const float p = expf(x - Ms[i]) * Rl[i];
                 float pd = p;
                 if (dc.p > 0.f) pd = ((Kb[i * 2 + t] >> l31) & 1u) ? p * scale : 0.f;
                 pdn[qi][r] = pd;
@@ -740,10 +749,10 @@ __global__ __launch_bounds__(128 * NHG) void mhsa_bwd_mfma2_kernel(const float* 
     if (active) {
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt) {
-            put_T<DHP>(Ks + t * HT, dq[dt], dt, l31, h);
-            f32x16 o = zT_tile<DHP>(Qs, ds[0], dt, l31, h);        // dK^T[d][key]
-            zT_tile_acc<DHP>(o, Qs + HT, ds[1], dt, l31, h);
-            put_T<DHP>(Vs + t * HT, o, dt, l31, h);
+            put_T(Ks + t * HT, dq[dt], dt, l31, h, LD, dh);
+            f32x16 o = zT_tile(Qs, ds[0], dt, l31, h, LD);        // dK^T[d][key]
+            zT_tile_acc(o, Qs + HT, ds[1], dt, l31, h, LD);
+            put_T(Vs + t * HT, o, dt, l31, h, LD, dh);
         }
     }
     __syncthreads();
@@ -753,9 +762,9 @@ __global__ __launch_bounds__(128 * NHG) void mhsa_bwd_mfma2_kernel(const float* 
     if (active) {
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt) {
-            f32x16 o = zT_tile<DHP>(Gs, pdn[0], dt, l31, h);       // dV^T[d][key]
-            zT_tile_acc<DHP>(o, Gs + HT, pdn[1], dt, l31, h);
-            put_T<DHP>(Ks + t * HT, o, dt, l31, h);
+            f32x16 o = zT_tile(Gs, pdn[0], dt, l31, h, LD);       // dV^T[d][key]
+            zT_tile_acc(o, Gs + HT, pdn[1], dt, l31, h, LD);
+            put_T(Ks + t * HT, o, dt, l31, h, LD, dh);
         }
     }
     __syncthreads();
@@ -778,7 +787,7 @@ static int launch_fwd(const T* qkv, const int64_t* mask, T* ctx, float* row_max,
     const int dhp = dh <= 32 ? 32 : 64;
     const int hpg = dhp == 32 ? 4 : 2;
     const dim3 grid((unsigned)(N * ((H + hpg - 1) / hpg)));
-    const size_t lds = ((size_t)3 * hpg * 32 * (dhp + 1) + 32) * sizeof(float);
+    const size_t lds = ((size_t)3 * hpg * 32 * (dh | 1) + 32) * sizeof(float);
     if (dhp == 32) {
         hipLaunchKernelGGL((mhsa_fwd_mfma_kernel<32, T, 4>), grid, dim3(256), lds, s, qkv, mask, ctx, row_max, row_sum, S, H, dh, dc, vec);
     } else {
@@ -794,7 +803,7 @@ static int launch_bwd(const T* qkv, const int64_t* mask, const T* dctx, const fl
     const int dhp = dh <= 32 ? 32 : 64;
     const int hpg = dhp == 32 ? 4 : 2;
     const dim3 grid((unsigned)(N * ((H + hpg - 1) / hpg)));
-    const size_t lds = ((size_t)4 * hpg * 32 * (dhp + 1) + hpg * 160 + hpg * 32) * sizeof(float);
+    const size_t lds = ((size_t)4 * hpg * 32 * (dh | 1) + hpg * 128 + hpg * 32) * sizeof(float);
     if (dhp == 32) {
         static bool once = false;
         if (!once) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mhsa_bwd_mfma_kernel<32, T, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); once = true; }
@@ -832,7 +841,7 @@ int mhsa_fwd_mfma2(const float* qkv, const int64_t* mask, float* ctx, float* row
     const int hpg = dhp == 32 ? 2 : 1;
     const int vec = vec_width(qkv, ctx, H, dh, hpg);
     const dim3 grid((unsigned)(N * ((H + hpg - 1) / hpg)));
-    const size_t lds = ((size_t)3 * hpg * 64 * (dhp + 1) + 64) * sizeof(float);
+    const size_t lds = ((size_t)3 * hpg * 64 * (dh | 1) + 64) * sizeof(float);
     if (dhp == 32) hipLaunchKernelGGL((mhsa_fwd_mfma2_kernel<32, 2>), grid, dim3(256), lds, s, qkv, mask, ctx, row_max, row_sum, S, H, dh, dc, vec);
     else           hipLaunchKernelGGL((mhsa_fwd_mfma2_kernel<64, 1>), grid, dim3(128), lds, s, qkv, mask, ctx, row_max, row_sum, S, H, dh, dc, vec);
     return check_launch("mhsa_fwd_mfma2");
@@ -844,7 +853,7 @@ int mhsa_bwd_mfma2(const float* qkv, const int64_t* mask, const float* dctx, con
     const int hpg = dhp == 32 ? 2 : 1;
     const int vec = min(vec_width(qkv, dctx, H, dh, hpg), vec_width(dqkv, dqkv, H, dh, hpg));
     const dim3 grid((unsigned)(N * ((H + hpg - 1) / hpg)));
-    const size_t lds = ((size_t)4 * hpg * 64 * (dhp + 1) + hpg * 320 + hpg * 128) * sizeof(float);
+    const size_t lds = ((size_t)4 * hpg * 64 * (dh | 1) + hpg * 256 + hpg * 128) * sizeof(float);
     static bool once = false;
     if (!once) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mhsa_bwd_mfma2_kernel<32, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
