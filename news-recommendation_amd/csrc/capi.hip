@@ -603,6 +603,34 @@ size_t nr_tfm_layer_bwd_ws_bytes(int64_t N, int64_t Sq, int64_t D) {
     return b + wmax;
 }
 
+// The four weight-gradient products of the layer backward feed nothing inside the layer: with enough rows to matter they
+// run on a second stream of the same device (forked by events after the tensor each one reads is complete, joined before
+// the call returns), next to the input-gradient products, the LayerNorm and the attention backward of the main stream —
+// the partial last rounds of one kernel and the latency-bound phases of another then hold work of both.
+// NR_SIDE_STREAM=0 keeps everything on the caller's stream.
+struct SideStream { hipStream_t s = nullptr; hipEvent_t fork[4] = {}, join = nullptr; bool ok = false; };
+static SideStream* side_stream() {
+    static SideStream g_side[64];
+    static std::mutex mu;
+    static const bool enabled = !(getenv("NR_SIDE_STREAM") && atoi(getenv("NR_SIDE_STREAM")) == 0);
+    if (!enabled) return nullptr;
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+    std::lock_guard<std::mutex> lk(mu);
+    SideStream& ss = g_side[dev];
+    if (!ss.s) {
+        if (hipStreamCreateWithFlags(&ss.s, hipStreamNonBlocking) != hipSuccess) { ss.s = nullptr; return nullptr; }
+        ss.ok = hipEventCreateWithFlags(&ss.join, hipEventDisableTiming) == hipSuccess;
+        for (int i = 0; i < 4; ++i) ss.ok = ss.ok && hipEventCreateWithFlags(&ss.fork[i], hipEventDisableTiming) == hipSuccess;
+    }
+    return ss.ok ? &ss : nullptr;
+}
+struct SideJoin {                               // the main stream waits for the side stream on every way out
+    SideStream* ss; hipStream_t main;
+    ~SideJoin() { if (ss) { (void)hipEventRecord(ss->join, ss->s); (void)hipStreamWaitEvent(main, ss->join, 0); } }
+};
+static const int64_t SIDE_MIN_ROWS = getenv("NR_SIDE_MIN_ROWS") ? atoll(getenv("NR_SIDE_MIN_ROWS")) : 1024;
+
 static int tfm_layer_bwd(const float* dy, const float* x, const int64_t* mask, int64_t N, int64_t Sq, int64_t R, int64_t D, int64_t H, const nr_tfm_weights* w, float p_drop, uint64_t seed, uint32_t site_base, int mask_mode, const nr_tfm_saved* sv, nr_tfm_grads* g, float* dx, void* ws, size_t ws_bytes, const int* offs, const int* row_map, hipStream_t s) {
     NR_CHECK_ARG(N > 0 && Sq > 0 && D > 0 && H > 0 && D % H == 0 && R > 0, "tfm_layer_bwd: bad sizes");
     NR_CHECK_ARG(dy && x && mask && w && sv && g && dx, "tfm_layer_bwd: null pointer");
@@ -626,21 +654,28 @@ static int tfm_layer_bwd(const float* dy, const float* x, const int64_t* mask, i
     const float* mean1 = sv->stats, *rstd1 = sv->stats + R, *mean2 = sv->stats + 2 * R, *rstd2 = sv->stats + 3 * R;
     const float* wqkv = contiguous3(w->wq, w->wk, w->wv, DD) ? w->wq : sv->wqkv;
     NR_CHECK_ARG(wqkv, "tfm_layer_bwd: q/k/v weights are not contiguous and no packed copy saved");
+    SideStream* ss = R >= SIDE_MIN_ROWS ? side_stream() : nullptr;
+    SideJoin join{ss, s};
+    const hipStream_t sw = ss ? ss->s : s;                   // stream of the weight-gradient products
+    auto fork = [&](int i) { if (ss) { (void)hipEventRecord(ss->fork[i], s); (void)hipStreamWaitEvent(sw, ss->fork[i], 0); } };
 
     // LN2 <- dy
     if (int rc = layernorm_bwd(dy, sv->s2, mean2, rstd2, w->ln2_g, R, (int)D, DCP(DC(p_drop, seed, site_base + 2), nullptr, row_map), ds2,
                                p_drop > 0.f ? dh2 : nullptr, g->dln2_g, g->dln2_b, lnws, s)) return rc;
     // FFN2: dW2 = dh2^T a ; dz = (dh2 W2) * gelu'(z)
-    if (int rc = linear_bwd_weight(dh2, D, sv->a, 4 * D, R, D, 4 * D, g->dw2, g->db2, wws, wws_bytes, 0, 0, s)) return rc;
+    fork(0);
+    if (int rc = linear_bwd_weight(dh2, D, sv->a, 4 * D, R, D, 4 * D, g->dw2, g->db2, wws, wws_bytes, 0, 0, sw)) return rc;
     if (int rc = linear_bwd_input(dh2, D, w->w2, R, D, 4 * D, EPI_MUL_GELU_GRAD, sv->z, nullptr, dz, s)) return rc;
     // FFN1: dW1 = dz^T y1 ; dy1 = dz W1 + ds2 (residual)
-    if (int rc = linear_bwd_weight(dz, 4 * D, sv->y1, D, R, 4 * D, D, g->dw1, g->db1, wws, wws_bytes, 0, 0, s)) return rc;
+    fork(1);
+    if (int rc = linear_bwd_weight(dz, 4 * D, sv->y1, D, R, 4 * D, D, g->dw1, g->db1, wws, wws_bytes, 0, 0, sw)) return rc;
     if (int rc = linear_bwd_input(dz, 4 * D, w->w1, R, 4 * D, D, EPI_ADD_AUX, ds2, nullptr, dy1, s)) return rc;
     // LN1
     if (int rc = layernorm_bwd(dy1, sv->s1, mean1, rstd1, w->ln1_g, R, (int)D, DCP(DC(p_drop, seed, site_base + 1), nullptr, row_map), ds1,
                                p_drop > 0.f ? dh1 : nullptr, g->dln1_g, g->dln1_b, lnws, s)) return rc;
     // attention output projection
-    if (int rc = linear_bwd_weight(dh1, D, sv->ctx, D, R, D, D, g->dwo, g->dbo, wws, wws_bytes, 0, 0, s)) return rc;
+    fork(2);
+    if (int rc = linear_bwd_weight(dh1, D, sv->ctx, D, R, D, D, g->dwo, g->dbo, wws, wws_bytes, 0, 0, sw)) return rc;
     if (int rc = linear_bwd_input(dh1, D, w->wo, R, D, D, EPI_NONE, nullptr, nullptr, dctx, s)) return rc;
     // attention core
     if (int rc = mhsa_bwd(sv->qkv, mask, sv->ctx, dctx, sv->row_max, sv->row_sum, dqkv, N, (int)Sq, (int)H, (int)(D / H),
@@ -649,13 +684,14 @@ static int tfm_layer_bwd(const float* dy, const float* x, const int64_t* mask, i
     const bool gcontig = contiguous3(g->dwq, g->dwk, g->dwv, DD) && contiguous3(g->dbq, g->dbk, g->dbv, (size_t)D);
     float* dwp = gcontig ? g->dwq : dwqkv;
     float* dbp = gcontig ? g->dbq : dbqkv;
-    if (int rc = linear_bwd_weight(dqkv, 3 * D, x, D, R, 3 * D, D, dwp, dbp, wws, wws_bytes, 0, 0, s)) return rc;
+    fork(3);
+    if (int rc = linear_bwd_weight(dqkv, 3 * D, x, D, R, 3 * D, D, dwp, dbp, wws, wws_bytes, 0, 0, sw)) return rc;
     if (!gcontig) {
         float* dws[3] = {g->dwq, g->dwk, g->dwv};
         float* dbs[3] = {g->dbq, g->dbk, g->dbv};
         for (int i = 0; i < 3; ++i) {
-            if (int rc = copy_d2d(dws[i], dwqkv + i * DD, DD * sizeof(float), s)) return rc;
-            if (int rc = copy_d2d(dbs[i], dbqkv + i * D, D * sizeof(float), s)) return rc;
+            if (int rc = copy_d2d(dws[i], dwqkv + i * DD, DD * sizeof(float), sw)) return rc;
+            if (int rc = copy_d2d(dbs[i], dbqkv + i * D, D * sizeof(float), sw)) return rc;
         }
     }
     return linear_bwd_input(dqkv, 3 * D, wqkv, R, 3 * D, D, EPI_ADD_AUX, ds1, nullptr, dx, s);

@@ -7,6 +7,7 @@ error, not a cue to fall back (there is nothing to fall back to).
 """
 import ctypes as C
 import math
+import os
 
 import torch
 
@@ -212,16 +213,55 @@ def linear_bwd_input(dy, w, mode=0, aux=None, aux2=None):
     return dx
 
 
-def linear_bwd_weight(dy, x2d, want_bias=True):
+def linear_bwd_weight(dy, x2d, want_bias=True, stream=None, keep=None):
+    """stream: launch there instead of on the current stream.  keep: a list that receives the workspace tensor — a caller
+    that launches on another stream holds it until that stream has been joined (the caching allocator would otherwise
+    hand the block to the next allocation of the current stream at once)."""
     R, N = dy.shape
     K = x2d.shape[1]
     dw = torch.empty(N, K, dtype=torch.float32, device=dy.device)
     db = torch.empty(N, dtype=torch.float32, device=dy.device) if want_bias else None
     nbytes = lib().nr_linear_bwd_weight_ws_bytes(R, N, K)
     ws = _ws(nbytes, dy.device)
-    check(lib().nr_linear_bwd_weight_f32(_p(dy), _p(x2d), R, N, K, _p(dw), _p(db), _p(ws), ws.numel() * 4, _stream()),
-          "nr_linear_bwd_weight_f32")
+    check(lib().nr_linear_bwd_weight_f32(_p(dy), _p(x2d), R, N, K, _p(dw), _p(db), _p(ws), ws.numel() * 4,
+                                         _stream() if stream is None else stream.cuda_stream), "nr_linear_bwd_weight_f32")
+    if keep is not None:
+        keep.append(ws)
     return dw, db
+
+
+# A layer's weight gradient feeds nothing else in its backward: with enough rows it runs on a second stream beside the
+# input-gradient product (the library does the same inside nr_tfm_layer_bwd_f32).  Every tensor is allocated on the
+# caller's stream and the caller's stream waits for the side stream before the backward returns, so the caching
+# allocator never sees the second stream.  NR_SIDE_STREAM=0 turns it off.
+_SIDE = {}
+_SIDE_MIN_ROWS = int(os.environ.get("NR_SIDE_MIN_ROWS", "1024"))
+
+
+def _side_stream(device, rows):
+    if rows < _SIDE_MIN_ROWS or os.environ.get("NR_SIDE_STREAM") == "0" or torch.device(device).type != "cuda":
+        return None
+    key = torch.device(device).index
+    if key not in _SIDE:
+        _SIDE[key] = torch.cuda.Stream(device=device)
+    return _SIDE[key]
+
+
+def linear_bwd_both(dy, w, x2d, want_input, want_bias=True, mode=0, aux=None, aux2=None):
+    """(dx or None, dw, db): dW = dy^T x on the side stream while dX = dy W runs on the current one"""
+    side = _side_stream(dy.device, dy.shape[0]) if want_input else None
+    if side is None:
+        dx = linear_bwd_input(dy, w, mode, aux, aux2) if want_input else None
+        dw, db = linear_bwd_weight(dy, x2d, want_bias)
+        return dx, dw, db
+    main = torch.cuda.current_stream(dy.device)
+    side.wait_stream(main)
+    held = []
+    dw, db = linear_bwd_weight(dy, x2d, want_bias, stream=side, keep=held)
+    dx = linear_bwd_input(dy, w, mode, aux, aux2)
+    main.wait_stream(side)
+    del held                                    # the workspace may be reused only now
+    return dx, dw, db
 
 
 class _Linear(torch.autograd.Function):
@@ -238,9 +278,8 @@ class _Linear(torch.autograd.Function):
     def backward(ctx, g):
         x2, w = ctx.saved_tensors
         g2 = _f32(g, "grad").reshape(-1, w.shape[0])
-        dx = linear_bwd_input(g2, w).view(ctx.xshape) if ctx.needs_input_grad[0] else None
-        dw, db = linear_bwd_weight(g2, x2, ctx.has_bias)
-        return dx, dw, db
+        dx, dw, db = linear_bwd_both(g2, w, x2, ctx.needs_input_grad[0], ctx.has_bias)
+        return (dx.view(ctx.xshape) if dx is not None else None), dw, db
 
 
 def linear(x, w, b=None):
@@ -265,9 +304,8 @@ class _LinearGelu(torch.autograd.Function):
         g2 = _f32(g, "grad").reshape(-1, w.shape[0])
         dz = torch.empty_like(g2)
         check(lib().nr_gelu_bwd_f32(_p(g2), _p(z), g2.numel(), _p(dz), _stream()), "nr_gelu_bwd_f32")
-        dx = linear_bwd_input(dz, w).view(ctx.xshape) if ctx.needs_input_grad[0] else None
-        dw, db = linear_bwd_weight(dz, x2, True)
-        return dx, dw, db
+        dx, dw, db = linear_bwd_both(dz, w, x2, ctx.needs_input_grad[0], True)
+        return (dx.view(ctx.xshape) if dx is not None else None), dw, db
 
 
 def linear_gelu(x, w, b):
@@ -772,9 +810,8 @@ class _ProjPool(torch.autograd.Function):
             check(L.nr_query_pool_packed_bwd_f32(_p(key), _p(x), _p(plan.offs), R, _p(query), _p(prob), _p(g), nseq, S, D, 1,
                                                  _p(dkeypre), _p(dvalue), _p(dq), _p(ws), ws.numel() * 4, _stream()),
                   "nr_query_pool_packed_bwd_f32")
-        dx = linear_bwd_input(dkeypre, w, 1, dvalue).view(x.shape)          # dkeypre W + dvalue
-        dw, db = linear_bwd_weight(dkeypre, x.view(-1, D))
-        return dx, dw, db, dq, None, None
+        dx, dw, db = linear_bwd_both(dkeypre, w, x.view(-1, D), True, True, 1, dvalue)          # dx = dkeypre W + dvalue
+        return dx.view(x.shape), dw, db, dq, None, None
 
 
 def project_and_pool(x, w, b, query, mask, plan=None):
