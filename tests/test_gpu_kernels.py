@@ -58,6 +58,42 @@ def test_gather_multi_dim_ids_and_grad(ops):
     assert t_gpu.grad[0].abs().max().item() == 0.0
 
 
+@pytest.mark.parametrize("pattern", ["one id", "every title has [CLS] and [SEP]", "20 repeated ids in a window", "all distinct", "ragged tail",
+                                     "pad and out-of-range ids"])
+def test_scatter_add_repeated_ids(ops, pattern):
+    """the embedding backward sums the rows of a 128-row window that share an id in LDS (at most 8 distinct repeated ids
+    per window, the rest by table atomics): every id pattern must give the plain index_add (reference: nn.Embedding's
+    backward, encoder.py:48-58 via autograd), PAD rows and out-of-range ids contributing nothing"""
+    from newsrec_hip.ops import _p, _stream, check, lib
+    g = G(77)
+    V, E = 1000, 300
+    n = {"ragged tail": 128 * 3 + 5, "one id": 700}.get(pattern, 128 * 6)
+    if pattern == "one id":
+        ids = torch.full((n,), 17)
+    elif pattern == "every title has [CLS] and [SEP]":
+        ids = torch.randint(200, V, (n,), generator=g)
+        ids[::20] = 101
+        ids[19::20] = 102
+    elif pattern == "20 repeated ids in a window":
+        ids = torch.arange(n) % 20 + 3                      # 20 ids, each 6-7 times per window: 8 take LDS slots, 12 do not
+    elif pattern == "all distinct":
+        ids = torch.randperm(V, generator=g)[:n]
+    elif pattern == "ragged tail":
+        ids = torch.randint(1, 40, (n,), generator=g)
+    else:
+        ids = torch.randint(0, 30, (n,), generator=g)       # id 0 = PAD
+        ids[5::11] = V + 7
+        ids[6::13] = -3
+    rows = torch.randn(n, E, generator=g)
+    ok = (ids > 0) & (ids < V)
+    ref = torch.zeros(V, E, dtype=torch.float64).index_add_(0, ids[ok], rows[ok].double())
+    out = torch.zeros(V, E, device="cuda")
+    rows_d, ids_d = rows.cuda(), ids.cuda()                 # held: the call is asynchronous
+    check(lib().nr_scatter_add_rows_f32(_p(rows_d), _p(ids_d), n, E, V, 0, _p(out), _stream()), "nr_scatter_add_rows_f32")
+    assert relerr(out, ref.float()) < FP32_TOL
+    assert out[0].abs().max().item() == 0.0
+
+
 # ------------------------------------------------------------------ dense layers (f32 GEMMs)
 @pytest.fixture(params=["fp32", "fp32-mfma"])
 def f32_gemm(request, ops):
