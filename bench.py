@@ -408,11 +408,15 @@ def main():
         d, _l = timed_steps(step, fence, args.steps, 0, world, reduce_max)
         rep.append(1000.0 * d / args.steps)
 
-    # ---- roofline leg: same steps with HIP events around every launch of each kernel family
+    # ---- roofline leg: same steps with HIP events around every launch of each kernel family.  The timed region above runs
+    # the weight-gradient products on a second stream; a kernel's duration only means something when it has the chip to
+    # itself, so this leg (and tools/profile.sh, whose rocprof durations it must agree with) runs them one at a time.
+    ops.set_side_stream(False)
     ops.prof_enable(True)
     for i in range(args.steps):
         step(i, time_sync=True)
     torch.cuda.synchronize()
+    ops.set_side_stream(True)
     allreduce = None
     if world > 1:
         ar_ms = sum(a.elapsed_time(b) for a, b in ar_events) / max(len(ar_events), 1)
@@ -446,6 +450,8 @@ def main():
                     **pmc_traffic("gemm_split_family"),
                     "launches_per_step": gs["launches_per_step"], "avg_launch_ms": round(gs["ms_per_step"] / max(gs["launches_per_step"], 1), 5),
                     "flops_per_step": gs["work_per_step"],
+                    "timing_note": "kernel durations measured with the kernels running one at a time (nr_set_side_stream(0)); the timed region of "
+                                   "`value` overlaps the weight-gradient products with the rest of the backward on a second stream",
                     "other_gemm_launches": {**fam_line(gm), "kernel": "gemm_x3s_kernel (the same arithmetic on 64x64 tiles, eight waves splitting the k-tile): products with too few "
                                                                       "tiles for gemm_x3_kernel (the user tower's 1 600 rows); latency-bound 125-475-workgroup grids",
                                             "peak": peak, "frac": round(tfl(gm) / peak, 4)},

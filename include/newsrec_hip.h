@@ -61,6 +61,11 @@ int nr_prof_read(int family, double* ms, int64_t* launches, double* work);
  * 1e-2); the closest thing in the reference is running the model under torch.autocast.  Process-wide and sticky:
  * set it before the first step.  nr_set_gemm_compute returns NR_ERR_ARG for an unknown mode. */
 int nr_set_gemm_compute(int mode);
+/* (no counterpart in the reference) nr_tfm_layer_bwd_f32 / nr_tfm_layer_packed_bwd_f32 run their four weight-gradient products
+ * on a second stream of the same GPU when the layer has >= 1024 rows (forked and joined by events inside the call: the caller
+ * sees the same ordering on its own stream).  nr_set_side_stream(0) keeps everything on the caller's stream, e.g. to time
+ * kernels one at a time; returns the previous setting.  NR_SIDE_STREAM=0 in the environment sets the initial value. */
+int nr_set_side_stream(int on);
 int nr_get_gemm_compute(void);
 
 /* ---- (i) token-embedding gather — nn.Embedding lookup, models/modules/encoder.py:52,135 ------

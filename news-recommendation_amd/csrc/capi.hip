@@ -7,12 +7,15 @@
 
 #include <stdarg.h>
 #include <cstdlib>
+#include <atomic>
 #include <mutex>
 #include <vector>
 
 namespace nr {
 
 static thread_local char g_err[512] = "";
+// weight-gradient products of a layer backward on a second stream (see tfm_layer_bwd); nr_set_side_stream
+static std::atomic<int> g_side_on{(getenv("NR_SIDE_STREAM") && atoi(getenv("NR_SIDE_STREAM")) == 0) ? 0 : 1};
 
 void set_error(const char* fmt, ...) {
     va_list ap;
@@ -148,6 +151,10 @@ int nr_set_gemm_compute(int mode) {
     NR_CHECK_ARG(mode == 0 || mode == 1 || mode == 2, "nr_set_gemm_compute: mode must be 0 (fp32 instruction), 1 (bf16 operands) or 2 (fp32 from three bf16 pieces)");
     nr::set_gemm_compute(mode);
     return NR_OK;
+}
+
+int nr_set_side_stream(int on) {
+    return g_side_on.exchange(on ? 1 : 0);
 }
 int nr_get_gemm_compute(void) { return nr::get_gemm_compute(); }
 const char* nr_last_error(void) { return g_err; }
@@ -607,13 +614,12 @@ size_t nr_tfm_layer_bwd_ws_bytes(int64_t N, int64_t Sq, int64_t D) {
 // run on a second stream of the same device (forked by events after the tensor each one reads is complete, joined before
 // the call returns), next to the input-gradient products, the LayerNorm and the attention backward of the main stream —
 // the partial last rounds of one kernel and the latency-bound phases of another then hold work of both.
-// NR_SIDE_STREAM=0 keeps everything on the caller's stream.
+// NR_SIDE_STREAM=0 in the environment or nr_set_side_stream(0) keeps everything on the caller's stream.
 struct SideStream { hipStream_t s = nullptr; hipEvent_t fork[4] = {}, join = nullptr; bool ok = false; };
 static SideStream* side_stream() {
     static SideStream g_side[64];
     static std::mutex mu;
-    static const bool enabled = !(getenv("NR_SIDE_STREAM") && atoi(getenv("NR_SIDE_STREAM")) == 0);
-    if (!enabled) return nullptr;
+    if (!g_side_on.load()) return nullptr;
     int dev = -1;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
     std::lock_guard<std::mutex> lk(mu);

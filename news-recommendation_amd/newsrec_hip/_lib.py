@@ -48,6 +48,7 @@ _SIGS = {
     "nr_prof_enable": (c_int, [c_int]),
     "nr_index_status": (c_int, [C.POINTER(c_int), c_fp]),
     "nr_set_gemm_compute": (c_int, [c_int]),
+    "nr_set_side_stream": (c_int, [c_int]),
     "nr_get_gemm_compute": (c_int, []),
     "nr_prof_read": (c_int, [c_int, C.POINTER(C.c_double), C.POINTER(c_i64), C.POINTER(C.c_double)]),
     "nr_gather_rows_f32": (c_int, [c_fp, c_i64, c_i64, c_fp, c_i64, c_fp, c_fp, c_fp]),

@@ -238,8 +238,20 @@ _SIDE = {}
 _SIDE_MIN_ROWS = int(os.environ.get("NR_SIDE_MIN_ROWS", "1024"))
 
 
+_SIDE_ON = os.environ.get("NR_SIDE_STREAM") != "0"
+
+
+def set_side_stream(on):
+    """weight-gradient products on a second stream (here and inside the library's layer backward): on by default; off
+    runs every kernel on the current stream, one at a time (what a per-kernel timing wants).  Returns the old setting."""
+    global _SIDE_ON
+    old, _SIDE_ON = _SIDE_ON, bool(on)
+    lib().nr_set_side_stream(1 if on else 0)
+    return old
+
+
 def _side_stream(device, rows):
-    if rows < _SIDE_MIN_ROWS or os.environ.get("NR_SIDE_STREAM") == "0" or torch.device(device).type != "cuda":
+    if rows < _SIDE_MIN_ROWS or not _SIDE_ON or torch.device(device).type != "cuda":
         return None
     key = torch.device(device).index
     if key not in _SIDE:
