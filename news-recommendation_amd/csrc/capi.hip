@@ -246,12 +246,44 @@ size_t nr_conv1d_k3_bwd_ws_bytes(int64_t M, int64_t T, int64_t E, int64_t D) {
     return pad256((size_t)D * 3 * E) + bwd_weight_ws(M * T, D, 3 * E, true);
 }
 
+// The four weight-gradient products of the layer backward feed nothing inside the layer: with enough rows to matter they
+// run on a second stream of the same device (forked by events after the tensor each one reads is complete, joined before
+// the call returns), next to the input-gradient products, the LayerNorm and the attention backward of the main stream —
+// the partial last rounds of one kernel and the latency-bound phases of another then hold work of both.
+// NR_SIDE_STREAM=0 in the environment or nr_set_side_stream(0) keeps everything on the caller's stream.
+struct SideStream { hipStream_t s = nullptr; hipEvent_t fork[4] = {}, join = nullptr; bool ok = false; };
+static SideStream* side_stream() {
+    static SideStream g_side[64];
+    static std::mutex mu;
+    if (!g_side_on.load()) return nullptr;
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+    std::lock_guard<std::mutex> lk(mu);
+    SideStream& ss = g_side[dev];
+    if (!ss.s) {
+        if (hipStreamCreateWithFlags(&ss.s, hipStreamNonBlocking) != hipSuccess) { ss.s = nullptr; return nullptr; }
+        ss.ok = hipEventCreateWithFlags(&ss.join, hipEventDisableTiming) == hipSuccess;
+        for (int i = 0; i < 4; ++i) ss.ok = ss.ok && hipEventCreateWithFlags(&ss.fork[i], hipEventDisableTiming) == hipSuccess;
+    }
+    return ss.ok ? &ss : nullptr;
+}
+struct SideJoin {                               // the main stream waits for the side stream on every way out
+    SideStream* ss; hipStream_t main;
+    ~SideJoin() { if (ss) { (void)hipEventRecord(ss->join, ss->s); (void)hipStreamWaitEvent(main, ss->join, 0); } }
+};
+static const int64_t SIDE_MIN_ROWS = getenv("NR_SIDE_MIN_ROWS") ? atoll(getenv("NR_SIDE_MIN_ROWS")) : 1024;
+
 int nr_conv1d_k3_bwd_f32(const float* dy, const float* x, const float* wpack, int64_t M, int64_t T, int64_t E, int64_t D, float* dx, float* dw, float* db, void* ws, size_t ws_bytes, void* stream) {
     NR_CHECK_ARG(M >= 0 && T > 0 && E > 0 && D > 0, "conv1d_bwd: bad sizes");
     NR_CHECK_ARG(dy && x && wpack && dw, "conv1d_bwd: null pointer");
     if (ws_bytes < nr_conv1d_k3_bwd_ws_bytes(M, T, E, D) || !ws) { set_error("conv1d_bwd: workspace too small"); return NR_ERR_WORKSPACE; }
     hipStream_t s = S(stream);
     const int64_t R = M * T;
+    // the weight gradient (and its unpacking) on the second stream, beside the input gradient
+    SideStream* ss = (dx && R >= SIDE_MIN_ROWS) ? side_stream() : nullptr;
+    SideJoin join{ss, s};
+    const hipStream_t sw = ss ? ss->s : s;
+    if (ss) { (void)hipEventRecord(ss->fork[0], s); (void)hipStreamWaitEvent(sw, ss->fork[0], 0); }
     if (dx) {
         GemmParams p;
         p.A = dy - D; p.lda = D; p.B = wpack + D * 3 * E; p.ldb = 3 * D; p.C = dx; p.ldc = E;
@@ -262,8 +294,8 @@ int nr_conv1d_k3_bwd_f32(const float* dy, const float* x, const float* wpack, in
     char* cur = (char*)ws;
     float* gwf = bump(cur, (size_t)D * 3 * E);
     const size_t rest = ws_bytes - (size_t)(cur - (char*)ws);
-    if (int rc = linear_bwd_weight(dy, D, x - E, E, R, D, 3 * E, gwf, db, cur, rest, (int)T, (int)E, s)) return rc;
-    return conv_unpack_grad(gwf, dw, (int)D, (int)E, s);
+    if (int rc = linear_bwd_weight(dy, D, x - E, E, R, D, 3 * E, gwf, db, cur, rest, (int)T, (int)E, sw)) return rc;
+    return conv_unpack_grad(gwf, dw, (int)D, (int)E, sw);
 }
 
 int nr_add_layernorm_fwd_f32(const float* h, const float* x, int64_t x_period, const float* gamma, const float* beta, int64_t R, int64_t D, float eps, float p_drop, uint64_t seed, uint32_t site, float* y, float* s_out, float* mean, float* rstd, void* stream) {
@@ -609,33 +641,6 @@ size_t nr_tfm_layer_bwd_ws_bytes(int64_t N, int64_t Sq, int64_t D) {
     wmax = std::max(wmax, bwd_weight_ws(R, D, D, true));
     return b + wmax;
 }
-
-// The four weight-gradient products of the layer backward feed nothing inside the layer: with enough rows to matter they
-// run on a second stream of the same device (forked by events after the tensor each one reads is complete, joined before
-// the call returns), next to the input-gradient products, the LayerNorm and the attention backward of the main stream —
-// the partial last rounds of one kernel and the latency-bound phases of another then hold work of both.
-// NR_SIDE_STREAM=0 in the environment or nr_set_side_stream(0) keeps everything on the caller's stream.
-struct SideStream { hipStream_t s = nullptr; hipEvent_t fork[4] = {}, join = nullptr; bool ok = false; };
-static SideStream* side_stream() {
-    static SideStream g_side[64];
-    static std::mutex mu;
-    if (!g_side_on.load()) return nullptr;
-    int dev = -1;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
-    std::lock_guard<std::mutex> lk(mu);
-    SideStream& ss = g_side[dev];
-    if (!ss.s) {
-        if (hipStreamCreateWithFlags(&ss.s, hipStreamNonBlocking) != hipSuccess) { ss.s = nullptr; return nullptr; }
-        ss.ok = hipEventCreateWithFlags(&ss.join, hipEventDisableTiming) == hipSuccess;
-        for (int i = 0; i < 4; ++i) ss.ok = ss.ok && hipEventCreateWithFlags(&ss.fork[i], hipEventDisableTiming) == hipSuccess;
-    }
-    return ss.ok ? &ss : nullptr;
-}
-struct SideJoin {                               // the main stream waits for the side stream on every way out
-    SideStream* ss; hipStream_t main;
-    ~SideJoin() { if (ss) { (void)hipEventRecord(ss->join, ss->s); (void)hipStreamWaitEvent(main, ss->join, 0); } }
-};
-static const int64_t SIDE_MIN_ROWS = getenv("NR_SIDE_MIN_ROWS") ? atoll(getenv("NR_SIDE_MIN_ROWS")) : 1024;
 
 static int tfm_layer_bwd(const float* dy, const float* x, const int64_t* mask, int64_t N, int64_t Sq, int64_t R, int64_t D, int64_t H, const nr_tfm_weights* w, float p_drop, uint64_t seed, uint32_t site_base, int mask_mode, const nr_tfm_saved* sv, nr_tfm_grads* g, float* dx, void* ws, size_t ws_bytes, const int* offs, const int* row_map, hipStream_t s) {
     NR_CHECK_ARG(N > 0 && Sq > 0 && D > 0 && H > 0 && D % H == 0 && R > 0, "tfm_layer_bwd: bad sizes");

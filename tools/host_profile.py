@@ -18,6 +18,7 @@ batches = [{k: v.cuda() for k, v in bench.synth_train_batch(g, 32, bench.NEWS_TR
 def step(i):
     opt.zero_grad(set_to_none=True)
     loss = model(batches[i % 8])
+    model.plan_ahead(batches[(i + 1) % 8])            # as bench.py / Manager._train: no device->host wait in the step
     loss.backward()
     opt.step()
 
