@@ -251,7 +251,15 @@ size_t nr_conv1d_k3_bwd_ws_bytes(int64_t M, int64_t T, int64_t E, int64_t D) {
 // the call returns), next to the input-gradient products, the LayerNorm and the attention backward of the main stream —
 // the partial last rounds of one kernel and the latency-bound phases of another then hold work of both.
 // NR_SIDE_STREAM=0 in the environment or nr_set_side_stream(0) keeps everything on the caller's stream.
-struct SideStream { hipStream_t s = nullptr; hipEvent_t fork[4] = {}, join = nullptr; bool ok = false; };
+struct SideStream {
+    hipStream_t s = nullptr; hipEvent_t fork[4] = {}, join = nullptr; bool ok = false;
+    std::mutex mu;                          // record + wait of one event as a pair: host threads may share the GPU
+    void edge(hipEvent_t ev, hipStream_t from, hipStream_t to) {
+        std::lock_guard<std::mutex> lk(mu);
+        (void)hipEventRecord(ev, from);
+        (void)hipStreamWaitEvent(to, ev, 0);
+    }
+};
 static SideStream* side_stream() {
     static SideStream g_side[64];
     static std::mutex mu;
@@ -269,7 +277,7 @@ static SideStream* side_stream() {
 }
 struct SideJoin {                               // the main stream waits for the side stream on every way out
     SideStream* ss; hipStream_t main;
-    ~SideJoin() { if (ss) { (void)hipEventRecord(ss->join, ss->s); (void)hipStreamWaitEvent(main, ss->join, 0); } }
+    ~SideJoin() { if (ss) ss->edge(ss->join, ss->s, main); }
 };
 static const int64_t SIDE_MIN_ROWS = getenv("NR_SIDE_MIN_ROWS") ? atoll(getenv("NR_SIDE_MIN_ROWS")) : 1024;
 
@@ -283,7 +291,7 @@ int nr_conv1d_k3_bwd_f32(const float* dy, const float* x, const float* wpack, in
     SideStream* ss = (dx && R >= SIDE_MIN_ROWS) ? side_stream() : nullptr;
     SideJoin join{ss, s};
     const hipStream_t sw = ss ? ss->s : s;
-    if (ss) { (void)hipEventRecord(ss->fork[0], s); (void)hipStreamWaitEvent(sw, ss->fork[0], 0); }
+    if (ss) ss->edge(ss->fork[0], s, sw);
     if (dx) {
         GemmParams p;
         p.A = dy - D; p.lda = D; p.B = wpack + D * 3 * E; p.ldb = 3 * D; p.C = dx; p.ldc = E;
@@ -668,7 +676,7 @@ static int tfm_layer_bwd(const float* dy, const float* x, const int64_t* mask, i
     SideStream* ss = R >= SIDE_MIN_ROWS ? side_stream() : nullptr;
     SideJoin join{ss, s};
     const hipStream_t sw = ss ? ss->s : s;                   // stream of the weight-gradient products
-    auto fork = [&](int i) { if (ss) { (void)hipEventRecord(ss->fork[i], s); (void)hipStreamWaitEvent(sw, ss->fork[i], 0); } };
+    auto fork = [&](int i) { if (ss) ss->edge(ss->fork[i], s, sw); };
 
     // LN2 <- dy
     if (int rc = layernorm_bwd(dy, sv->s2, mean2, rstd2, w->ln2_g, R, (int)D, DCP(DC(p_drop, seed, site_base + 2), nullptr, row_map), ds2,
