@@ -368,6 +368,43 @@ def test_mhsa(ops, N, S, H, dh, p):
         assert relerr(dq[:S], qr.grad[:S]) < 5e-2
 
 
+@pytest.mark.parametrize("N,S,H,dh", [(6, 20, 4, 16), (6, 50, 4, 16), (5, 64, 2, 64), (4, 96, 2, 16)])
+@pytest.mark.parametrize("p", [0.0, 0.1])
+def test_mhsa_minus_inf_mask(ops, N, S, H, dh, p):
+    """mask_mode 1 = the HF / SDPA convention of the BERT encoder (masked keys at -inf, a row without a valid key gives
+    zeros, not NaN): one-tile, two-tile and scalar kernels against the same arithmetic in torch"""
+    g = G(81)
+    A = H * dh
+    qkv = torch.randn(N * S, 3 * A, generator=g)
+    lens = torch.randint(1, S + 1, (N,), generator=g)
+    mask = (torch.arange(S)[None] < lens[:, None]).long()
+    mask[0] = 0                                          # no valid key at all
+    dctx = torch.randn(N * S, A, generator=g)
+    seed, site = 5, 2
+    keep = keep_mask((N, H, S, S), p, seed, site) if p > 0 else None
+    qr = qkv.clone().requires_grad_(True)
+    q, k, v = [t.reshape(N, S, H, dh).permute(0, 2, 1, 3) for t in qr.reshape(N, S, 3, A).unbind(2)]
+    sc = torch.matmul(q, k.transpose(-1, -2)) / math.sqrt(dh)
+    sc = sc.masked_fill(mask[:, None, None, :] == 0, float("-inf"))
+    pr = torch.nan_to_num(torch.softmax(sc, -1), nan=0.0)
+    ref = torch.matmul(O._drop(pr, keep, p), v).permute(0, 2, 1, 3).reshape(N * S, A)
+    ref.backward(dctx)
+    L = ops.lib()
+    st = torch.cuda.current_stream().cuda_stream
+    qg, mg, dcg = qkv.cuda(), mask.cuda(), dctx.cuda()
+    ctx = torch.empty(N * S, A, device="cuda")
+    rmax = torch.empty(N, H, S, device="cuda"); rsum = torch.empty(N, H, S, device="cuda")
+    ops.check(L.nr_mhsa_fwd_f32(qg.data_ptr(), mg.data_ptr(), N, S, H, dh, p, seed, site, 1, ctx.data_ptr(), rmax.data_ptr(),
+                                rsum.data_ptr(), st))
+    assert torch.isfinite(ctx).all() and ctx[:S].abs().max().item() == 0.0
+    assert relerr(ctx, ref) < FP32_TOL
+    dq = torch.empty(N * S, 3 * A, device="cuda")
+    ops.check(L.nr_mhsa_bwd_f32(qg.data_ptr(), mg.data_ptr(), ctx.data_ptr(), dcg.data_ptr(), rmax.data_ptr(), rsum.data_ptr(),
+                                N, S, H, dh, p, seed, site, 1, dq.data_ptr(), st))
+    assert torch.isfinite(dq).all()
+    assert relerr(dq, qr.grad) < 2e-5
+
+
 def test_mhsa_masked_quantisation_exact(ops):
     """integer-valued inputs make every dot product exact, so the kernel must reproduce the
     reference's fl32(score/sqrt(dh) - 1e5) quantisation on a fully masked row BIT FOR BIT-ish."""
