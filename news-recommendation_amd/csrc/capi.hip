@@ -837,42 +837,53 @@ int nr_tfm_layer_bwd_bf16(const float* dy, const int64_t* mask, const int32_t* o
     float* slabs = reinterpret_cast<float*>(cur);
     const size_t slab_bytes = ws_bytes - (size_t)(cur - (char*)ws);
     const float* mean1 = sv->stats, *rstd1 = sv->stats + R, *mean2 = sv->stats + 2 * R, *rstd2 = sv->stats + 3 * R;
+    // Everything that only serves a weight / bias gradient (operand transposes, the dW product and its slab sum, the
+    // column sums) runs on the second stream, in order, so dhT / actT / dzT / cpart / slabs are reused there without
+    // hazards; the main stream keeps LayerNorm, the weight transposes, the dX products and the attention backward.
+    SideStream* ss = R >= SIDE_MIN_ROWS ? side_stream() : nullptr;
+    SideJoin join{ss, s};
+    const hipStream_t sw = ss ? ss->s : s;
+    auto fork = [&](int i) { if (ss) ss->edge(ss->fork[i], s, sw); };
 
     // LN2 <- dy
     if (int rc = layernorm_bwd(dy, sv->s2, mean2, rstd2, w->ln2_g, R, (int)D, DCP(DC(p_drop, seed, site_base + 2), nullptr, row_map), ds2, p_drop > 0.f ? dh2 : nullptr, g->dln2_g, g->dln2_b, lnws, s, dh_h)) return rc;
     // FFN2: dW2 [D,4D] = dh2^T a ; db2 ; dz = (dh2 W2) * gelu'(z)
-    if (int rc = transpose_bf16(dh2, 0, D, R, D, dhT, Rp, s)) return rc;
+    fork(0);
+    if (int rc = transpose_bf16(dh2, 0, D, R, D, dhT, Rp, sw)) return rc;
     const unsigned short* aT = sv->aT_h;
     if (!aT) {
-        if (int rc = transpose_bf16(sv->a_h, 1, 4 * D, R, 4 * D, actT, Rp, s)) return rc;
+        if (int rc = transpose_bf16(sv->a_h, 1, 4 * D, R, 4 * D, actT, Rp, sw)) return rc;
         aT = actT;
     }
-    if (int rc = gemm_dw(dhT, aT, D, 4 * D, Rp, g->dw2, slabs, slab_bytes, s)) return rc;
-    if (int rc = colsum(dh2, D, R, (int)D, g->db2, cpart, s)) return rc;
+    if (int rc = gemm_dw(dhT, aT, D, 4 * D, Rp, g->dw2, slabs, slab_bytes, sw)) return rc;
+    if (int rc = colsum(dh2, D, R, (int)D, g->db2, cpart, sw)) return rc;
     if (int rc = transpose_bf16(w->w2, 0, 4 * D, D, 4 * D, wT, D, s)) return rc;                       // [D,4D] -> [4D,D]
     if (int rc = gemm_nt(dh_h, D, wT, D, R, 4 * D, D, nullptr, EPI_MUL_GELU_GRAD, nullptr, dz_h, nullptr, sv->z_h, nullptr, s, dzT, Rp)) return rc;
     // FFN1: dW1 [4D,D] = dz^T y1 ; db1 ; dy1 = dz W1 + ds2   (dz^T came out of the product above)
-    if (int rc = transpose_bf16(sv->y1_h, 1, D, R, D, actT, Rp, s)) return rc;
-    if (int rc = gemm_dw(dzT, actT, 4 * D, D, Rp, g->dw1, slabs, slab_bytes, s)) return rc;
-    if (int rc = colsum_h(dz_h, 4 * D, R, (int)(4 * D), g->db1, cpart, s)) return rc;
+    fork(1);
+    if (int rc = transpose_bf16(sv->y1_h, 1, D, R, D, actT, Rp, sw)) return rc;
+    if (int rc = gemm_dw(dzT, actT, 4 * D, D, Rp, g->dw1, slabs, slab_bytes, sw)) return rc;
+    if (int rc = colsum_h(dz_h, 4 * D, R, (int)(4 * D), g->db1, cpart, sw)) return rc;
     if (int rc = transpose_bf16(w->w1, 0, D, 4 * D, D, wT, 4 * D, s)) return rc;                       // [4D,D] -> [D,4D]
     if (int rc = gemm_nt(dz_h, 4 * D, wT, 4 * D, R, D, 4 * D, nullptr, EPI_ADD_AUX, dy1, nullptr, ds2, nullptr, nullptr, s)) return rc;
     // LN1
     if (int rc = layernorm_bwd(dy1, sv->s1, mean1, rstd1, w->ln1_g, R, (int)D, DCP(DC(p_drop, seed, site_base + 1), nullptr, row_map), ds1, p_drop > 0.f ? dh1 : nullptr, g->dln1_g, g->dln1_b, lnws, s, dh_h)) return rc;
     // attention output projection: dWo = dh1^T ctx ; dbo ; dctx = dh1 Wo
-    if (int rc = transpose_bf16(dh1, 0, D, R, D, dhT, Rp, s)) return rc;
-    if (int rc = transpose_bf16(sv->ctx_h, 1, D, R, D, actT, Rp, s)) return rc;
-    if (int rc = gemm_dw(dhT, actT, D, D, Rp, g->dwo, slabs, slab_bytes, s)) return rc;
-    if (int rc = colsum(dh1, D, R, (int)D, g->dbo, cpart, s)) return rc;
+    fork(2);
+    if (int rc = transpose_bf16(dh1, 0, D, R, D, dhT, Rp, sw)) return rc;
+    if (int rc = transpose_bf16(sv->ctx_h, 1, D, R, D, actT, Rp, sw)) return rc;
+    if (int rc = gemm_dw(dhT, actT, D, D, Rp, g->dwo, slabs, slab_bytes, sw)) return rc;
+    if (int rc = colsum(dh1, D, R, (int)D, g->dbo, cpart, sw)) return rc;
     if (int rc = transpose_bf16(w->wo, 0, D, D, D, wT, D, s)) return rc;
     if (int rc = gemm_nt(dh_h, D, wT, D, R, D, D, nullptr, EPI_NONE, nullptr, dctx_h, nullptr, nullptr, nullptr, s)) return rc;
     // attention core
     if (int rc = mhsa_bwd_mfma_h(sv->qkv_h, mask, dctx_h, sv->row_max, sv->row_sum, dqkv_h, N, (int)Sq, (int)H, (int)(D / H), DCP(DCA(p_drop, seed, site_base, mask_mode), offs, nullptr), s)) return rc;
     // QKV projection: dWqkv [3D,D] = dqkv^T x ; dbqkv ; dx = dqkv Wqkv + ds1
-    if (int rc = transpose_bf16(dqkv_h, 1, 3 * D, R, 3 * D, dzT, Rp, s)) return rc;
-    if (int rc = transpose_bf16(sv->x_h, 1, D, R, D, actT, Rp, s)) return rc;
-    if (int rc = gemm_dw(dzT, actT, 3 * D, D, Rp, g->dwq, slabs, slab_bytes, s)) return rc;
-    if (int rc = colsum_h(dqkv_h, 3 * D, R, (int)(3 * D), g->dbq, cpart, s)) return rc;
+    fork(3);
+    if (int rc = transpose_bf16(dqkv_h, 1, 3 * D, R, 3 * D, dzT, Rp, sw)) return rc;
+    if (int rc = transpose_bf16(sv->x_h, 1, D, R, D, actT, Rp, sw)) return rc;
+    if (int rc = gemm_dw(dzT, actT, 3 * D, D, Rp, g->dwq, slabs, slab_bytes, sw)) return rc;
+    if (int rc = colsum_h(dqkv_h, 3 * D, R, (int)(3 * D), g->dbq, cpart, sw)) return rc;
     if (int rc = transpose_bf16(w->wq, 0, D, 3 * D, D, wT, 3 * D, s)) return rc;                       // [3D,D] -> [D,3D]
     return gemm_nt(dqkv_h, 3 * D, wT, 3 * D, R, D, 3 * D, nullptr, EPI_ADD_AUX, dx, nullptr, ds1, nullptr, nullptr, s);
 }
