@@ -3,7 +3,8 @@ import csv, glob, sys
 d = sys.argv[1]
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 50
 steps = float(sys.argv[3]) if len(sys.argv) > 3 else 0
-rows = list(csv.DictReader(open(glob.glob(d + "/**/*kernel_stats.csv", recursive=True)[0])))
+import os
+rows = list(csv.DictReader(open(max(glob.glob(d + "/**/*kernel_stats.csv", recursive=True), key=os.path.getmtime))))
 tot = sum(float(r["TotalDurationNs"]) for r in rows)
 print("total ms", round(tot / 1e6, 3), " per step" if steps else "", round(tot / 1e6 / steps, 4) if steps else "")
 for r in rows[:n]:

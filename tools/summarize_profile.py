@@ -16,8 +16,9 @@ def short(name):
     return name[:90]
 
 def one(pattern):
+    # a profile directory collects one file set per run (the file names carry the process id): take the newest
     fs = glob.glob(os.path.join(src, pattern), recursive=True)
-    return fs[0] if fs else None
+    return max(fs, key=os.path.getmtime) if fs else None
 
 out = {}
 stats = one("trace/**/*kernel_stats.csv")
