@@ -22,7 +22,15 @@ def lib():
     return _lib.load()
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+_cur_device = getattr(torch._C, "_cuda_getDevice", None)
+
+
 def _stream():
+    """handle of the current stream of the current device (the raw query: torch.cuda.current_stream() builds a Stream
+    object per call, and a train step asks sixty times)"""
+    if _raw_stream is not None and _cur_device is not None:
+        return _raw_stream(_cur_device())
     return torch.cuda.current_stream().cuda_stream
 
 
