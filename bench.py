@@ -398,6 +398,11 @@ def main():
         out = [float(x) for x in tt.tolist()]
         return out if isinstance(v, (list, tuple)) else out[0]
 
+    # as Manager._train does before its loop: a generation-2 garbage collection over the long-lived objects (model,
+    # tables, batches) costs 65-80 ms and would land in a timed region every few hundred steps
+    import gc
+    gc.collect()
+    gc.freeze()
     dt, loss = timed_steps(step, fence, args.steps, args.warmup, world, reduce_max)
     final_loss = float(loss)
     ms_per_step = 1000.0 * dt / args.steps

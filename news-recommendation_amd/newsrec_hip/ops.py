@@ -8,6 +8,7 @@ error, not a cue to fall back (there is nothing to fall back to).
 import ctypes as C
 import math
 import os
+import time
 
 import torch
 
@@ -157,6 +158,19 @@ class PendingPlan:
         self.offs, self.info, self.host, self.event, self.N, self.T, self.mask_ptr = offs, info, host, event, N, T, mask_ptr
 
 
+def _wait_event(event, spin_s=3e-3):
+    """wait for a short device->host hand-off by polling: in a GPU-bound loop the host arrives here a little early every
+    step, and a blocking hipEventSynchronize that goes to sleep wakes up late (measured: a step of 2.3 ms became 3.1 ms
+    whenever the host was 0.3 ms ahead of the GPU, tools/host_slack.py).  Long waits fall back to the blocking call."""
+    if event.query():
+        return
+    t0 = time.perf_counter()
+    while not event.query():
+        if time.perf_counter() - t0 > spin_s:
+            event.synchronize()
+            return
+
+
 def pack_titles_begin(mask, title_keep=None):
     """queue the plan of pack_titles for `mask` / `title_keep` without waiting for it.  A caller that knows its next
     batch (a training loop with one batch of look-ahead) starts the plan a step early, so that the row count is already
@@ -189,7 +203,7 @@ def pack_titles(ids, mask, title_keep=None, pending=None):
         pending = pack_titles_begin(mask, title_keep)
     elif (pending.N, pending.T, pending.mask_ptr) != (N, T, mask.data_ptr()):
         raise NewsrecError("pack_titles: the pending plan was started for another mask")
-    pending.event.synchronize()
+    _wait_event(pending.event)
     rows, ok = pending.host.tolist()
     if not ok:
         return None
@@ -1092,6 +1106,23 @@ def adam_multi(params, grads, exp_avgs, exp_avg_sqs, step, lr, beta1=0.9, beta2=
     numel = NT(*[t.numel() for t in params])
     check(lib().nr_adam_multi_f32(n, tabs[0], tabs[1], tabs[2], tabs[3], numel, lr, beta1, beta2, eps, step, _stream()),
           "nr_adam_multi_f32")
+
+
+def adam_tables(params, exp_avgs, exp_avg_sqs):
+    """the step-invariant part of adam_multi's arguments: pointer tables of the parameters and both moments, sizes.  The
+    tensors are kept alive by the tuple."""
+    n = len(params)
+    PT, NT = C.c_void_p * n, C.c_int64 * n
+    tabs = [PT(*[_p(t) for t in ts]) for ts in (params, exp_avgs, exp_avg_sqs)]
+    return n, tabs[0], tabs[1], tabs[2], NT(*[t.numel() for t in params]), PT, (tuple(params), tuple(exp_avgs), tuple(exp_avg_sqs))
+
+
+def adam_multi_cached(static, grads, step, lr, beta1=0.9, beta2=0.999, eps=1e-8):
+    n, tp, tm, tv, numel, PT, _keep = static
+    if len(grads) != n:
+        raise NewsrecError("adam_multi_cached: gradient list does not match the cached tables")
+    tg = PT(*[g.data_ptr() for g in grads])
+    check(lib().nr_adam_multi_f32(n, tp, tg, tm, tv, numel, lr, beta1, beta2, eps, step, _stream()), "nr_adam_multi_f32")
 
 
 # ----------------------------------------------------------------------------- profiler

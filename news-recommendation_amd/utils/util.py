@@ -225,6 +225,10 @@ class HipAdam(torch.optim.Optimizer):
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8):
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps))
 
+    def load_state_dict(self, state_dict):
+        super().load_state_dict(state_dict)
+        self._tables = {}                     # the moments are new tensors now
+
     @torch.no_grad()
     def step(self, closure=None):
         from newsrec_hip import ops
@@ -232,23 +236,43 @@ class HipAdam(torch.optim.Optimizer):
         if closure is not None:
             with torch.enable_grad():
                 loss = closure()
-        for group in self.param_groups:
+        for gi, group in enumerate(self.param_groups):
             b1, b2 = group["betas"]
-            by_step = {}                      # tensors that share a step number go into one launch
-            for p in group["params"]:
-                if p.grad is None:
-                    continue
-                st = self.state[p]
-                if not st:
-                    st["step"] = 0
-                    st["exp_avg"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
-                    st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
+            ps = [p for p in group["params"] if p.grad is not None]
+            if not ps:
+                continue
+            # everything about the step except the gradient pointers is the same from step to step (the same tensors get
+            # gradients, parameters and moments do not move): the pointer tables of the fused launch are built once
+            key = tuple((id(p), p.data_ptr()) for p in ps)      # a parameter moved by .to() / .data = ... rebuilds them
+            cache = getattr(self, "_tables", {}).get(gi)
+            if cache is None or cache["key"] != key:
+                for p in ps:
+                    st = self.state[p]
+                    if not st:
+                        st["step"] = 0
+                        st["exp_avg"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
+                        st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
+                    if not p.is_contiguous():     # the kernel walks flat memory
+                        raise RuntimeError("HipAdam: parameters must be contiguous")
+                states = [self.state[p] for p in ps]
+                cache = {"key": key, "states": states,
+                         "static": ops.adam_tables(ps, [st["exp_avg"] for st in states], [st["exp_avg_sq"] for st in states])}
+                if not hasattr(self, "_tables"):
+                    self._tables = {}
+                self._tables[gi] = cache
+            states = cache["states"]
+            steps = set()
+            for st in states:
                 st["step"] += 1
-                if not p.is_contiguous():     # the kernel walks flat memory; a strided parameter gets the per-tensor path
-                    raise RuntimeError("HipAdam: parameters must be contiguous")
-                g = p.grad if p.grad.is_contiguous() else p.grad.contiguous()
-                by_step.setdefault(int(st["step"]), []).append((p, g, st["exp_avg"], st["exp_avg_sq"]))
-            for step, items in by_step.items():
-                ps, gs, ms, vs = zip(*items)
-                ops.adam_multi(ps, gs, ms, vs, step, float(group["lr"]), b1, b2, group["eps"])
+                steps.add(int(st["step"]))
+            gs = [p.grad if p.grad.is_contiguous() else p.grad.contiguous() for p in ps]
+            if len(steps) == 1:
+                ops.adam_multi_cached(cache["static"], gs, steps.pop(), float(group["lr"]), b1, b2, group["eps"])
+            else:                             # tensors that share a step number go into one launch
+                by_step = {}
+                for p, g, st in zip(ps, gs, states):
+                    by_step.setdefault(int(st["step"]), []).append((p, g, st["exp_avg"], st["exp_avg_sq"]))
+                for step, items in by_step.items():
+                    a, b, c, d = zip(*items)
+                    ops.adam_multi(a, b, c, d, step, float(group["lr"]), b1, b2, group["eps"])
         return loss

@@ -556,6 +556,41 @@ def test_adam_matches_torch(ops):
     assert relerr(m, opt.state[pr]["exp_avg"]) < 1e-6 and relerr(v, opt.state[pr]["exp_avg_sq"]) < 1e-6
 
 
+def test_hip_adam_optimizer_matches_torch_adam(ops):
+    """utils.util.HipAdam (one fused launch over cached pointer tables) against torch.optim.Adam on the CPU over the
+    situations that change its tables: a parameter that skips a step (its step count falls behind: grouped launches), a
+    state_dict round trip into a fresh optimizer, a parameter whose storage moves"""
+    from utils.util import HipAdam
+    g = G(15)
+    shapes = [(300, 300), (300,), (1200, 300), (7,), (30, 11)]
+    ref = [torch.randn(*sh, generator=g).requires_grad_(True) for sh in shapes]
+    dev = [r.detach().clone().cuda().requires_grad_(True) for r in ref]
+    o_ref, o_dev = torch.optim.Adam(ref, lr=1e-3), HipAdam(dev, lr=1e-3)
+
+    def one_step(skip=None):
+        for i, (r, d) in enumerate(zip(ref, dev)):
+            if i == skip:
+                r.grad = d.grad = None
+                continue
+            gr = torch.randn(r.shape, generator=g)
+            r.grad, d.grad = gr.clone(), gr.cuda()
+        o_ref.step(); o_dev.step()
+
+    def check_equal():
+        for r, d in zip(ref, dev):
+            assert relerr(d, r) < 1e-6
+    one_step(); one_step(); check_equal()
+    one_step(skip=3); one_step(); check_equal()                  # parameter 3 is one step behind from here on
+    o_dev2 = HipAdam(dev, lr=1e-3)
+    o_dev2.load_state_dict(o_dev.state_dict())
+    o_dev = o_dev2
+    one_step(); one_step(skip=0); one_step(); check_equal()
+    with torch.no_grad():
+        dev[2].data = dev[2].data.clone()                         # same Parameter object, new storage
+    one_step(); one_step(); check_equal()
+    assert o_dev.state[dev[3]]["step"] == o_ref.state[ref[3]]["step"] == 8
+
+
 # ------------------------------------------------------------------ GRU user encoder (final state of a packed batch)
 @pytest.mark.parametrize("B,L,D", [(32, 50, 300), (8, 50, 768), (5, 7, 24), (200, 50, 96), (1, 1, 8), (6, 9, 26)])
 def test_gru_final_state(ops, B, L, D):

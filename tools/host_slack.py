@@ -14,6 +14,20 @@ g = torch.Generator().manual_seed(1000)
 ids, msk = bench.synth_table(g, bench.NEWS_TRAIN)
 batches = [{k: v.cuda() for k, v in bench.synth_train_batch(g, 32, bench.NEWS_TRAIN, ids, msk).items()} for _ in range(8)]
 
+import gc
+_gc_t = {}
+def _gc_cb(phase, info):
+    if phase == "start":
+        _gc_t["t"] = time.perf_counter()
+    else:
+        dt = time.perf_counter() - _gc_t["t"]
+        if dt > 2e-3:
+            print(f"    gc gen{info['generation']} took {dt * 1e3:.1f} ms (collected {info['collected']})")
+gc.callbacks.append(_gc_cb)
+if os.environ.get("NR_GC_FREEZE") == "1":
+    gc.collect(); gc.freeze()
+
+
 def step(i, delay):
     opt.zero_grad(set_to_none=True)
     loss = model(batches[i % 8])
@@ -25,7 +39,7 @@ def step(i, delay):
         while time.perf_counter() < t:
             pass
 
-for delay in (0, 100, 200, 400, 800):
+for delay in [int(v) for v in (sys.argv[1:] or ["0", "100", "200", "400", "800"])]:
     for i in range(10):
         step(i, delay)
     torch.cuda.synchronize()
