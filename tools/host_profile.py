@@ -42,3 +42,6 @@ for key in ("cumulative", "tottime"):
     s = io.StringIO()
     pstats.Stats(pr, stream=s).sort_stats(key).print_stats(45)
     print(s.getvalue())
+s = io.StringIO()
+pstats.Stats(pr, stream=s).print_callers("_dict_flatten|tree_flatten|tree_map")
+print(s.getvalue()[:3000])
