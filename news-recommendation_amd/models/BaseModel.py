@@ -300,13 +300,15 @@ class TwoTowerBaseModel(BaseModel):
 
     def _predict(self, manager, loader, with_labels, to_host=True):
         """score this rank's shard; results stay on the device as flat typed tensors until the end."""
+        from utils.util import frozen_gc
         impr, masks, labels, preds = [], [], [], []
-        for x in tqdm(loader, ncols=80, desc="Predicting", disable=self.rank != 0):
-            preds.append(self.infer(x))
-            impr.append(x["impr_index"])
-            masks.append(x["cdd_mask"])
-            if with_labels:
-                labels.append(x["label"])
+        with frozen_gc():                       # thousands of batches: no full garbage collection over the datasets mid-loop
+            for x in tqdm(loader, ncols=80, desc="Predicting", disable=self.rank != 0):
+                preds.append(self.infer(x))
+                impr.append(x["impr_index"])
+                masks.append(x["cdd_mask"])
+                if with_labels:
+                    labels.append(x["label"])
         self._check_indices("infer")
         dev = self.device
         Ce = manager.impr_size

@@ -276,13 +276,9 @@ class Manager():
         # garbage collection walks all of them and was measured at 65-80 ms, every few hundred steps, in the middle of a
         # 2.3 ms step (tools/host_slack.py).  Moving what exists now to the permanent generation keeps collections to the
         # objects a step creates.
-        import gc
-        gc.collect()
-        gc.freeze()
-        try:
+        from utils.util import frozen_gc
+        with frozen_gc():
             return self._train_loop(model, core, loader, loaders, validate_step, hold_step, optimizer, scheduler, save_at_validate, best, total_steps)
-        finally:
-            gc.unfreeze()
 
     def _train_loop(self, model, core, loader, loaders, validate_step, hold_step, optimizer, scheduler, save_at_validate, best, total_steps):
         for epoch in range(self.epochs):

@@ -193,6 +193,29 @@ def device_compute_metrics(impr, masks, preds, labels, metrics):
     return res
 
 
+class frozen_gc:
+    """`with frozen_gc():` around a long loop: what is alive now (datasets, model, optimizer state — millions of Python
+    objects) moves to the garbage collector's permanent generation, so the collections that the loop's own garbage
+    triggers stay in the microseconds.  A full collection over those objects was measured at 65-80 ms, every few hundred
+    steps of a 2.3 ms step.  Re-entrant: the outermost exit thaws."""
+    depth = 0
+
+    def __enter__(self):
+        import gc
+        if frozen_gc.depth == 0:
+            gc.collect()
+            gc.freeze()
+        frozen_gc.depth += 1
+        return self
+
+    def __exit__(self, *exc):
+        import gc
+        frozen_gc.depth -= 1
+        if frozen_gc.depth == 0:
+            gc.unfreeze()
+        return False
+
+
 class Sequential_Sampler:
     """rank r reads the contiguous slice [round(n/ws*r), round(n/ws*(r+1)))"""
 
