@@ -317,16 +317,30 @@ size_t nr_layernorm_bwd_ws_bytes(int64_t R, int64_t D) {
     return 2 * pad256((size_t)ln_bwd_blocks(R) * D) + pad256((size_t)2 * colsum_chunks(ln_bwd_blocks(R)) * D);
 }
 
-static int layernorm_bwd(const float* dy, const float* s_in, const float* mean, const float* rstd, const float* gamma, int64_t R,
-                         int D, DropoutCfg dc, float* ds, float* dh, float* dgamma, float* dbeta, char* ws, hipStream_t s,
-                         unsigned short* dh_h = nullptr) {
+// the row pass (ds, dh and per-workgroup partials of dgamma / dbeta in `ws`) ...
+static int layernorm_bwd_rows(const float* dy, const float* s_in, const float* mean, const float* rstd, const float* gamma, int64_t R,
+                              int D, DropoutCfg dc, float* ds, float* dh, char* ws, hipStream_t s, unsigned short* dh_h = nullptr) {
+    char* cur = ws;
+    const int nb = ln_bwd_blocks(R);
+    float* pg = bump(cur, (size_t)nb * D);
+    float* pb = bump(cur, (size_t)nb * D);
+    return ln_bwd(dy, s_in, mean, rstd, gamma, ds, dh, pg, pb, R, D, dc, s, dh_h);
+}
+// ... and the two column sums that finish dgamma / dbeta (they feed nothing else: the layer backward runs them on its
+// second stream, which needs a `ws` of its own per LayerNorm)
+static int layernorm_bwd_params(int64_t R, int D, float* dgamma, float* dbeta, char* ws, hipStream_t s) {
     char* cur = ws;
     const int nb = ln_bwd_blocks(R);
     float* pg = bump(cur, (size_t)nb * D);
     float* pb = bump(cur, (size_t)nb * D);
     float* part = bump(cur, (size_t)2 * colsum_chunks(nb) * D);
-    if (int rc = ln_bwd(dy, s_in, mean, rstd, gamma, ds, dh, pg, pb, R, D, dc, s, dh_h)) return rc;
     return colsum2(pg, pb, nb, D, dgamma, dbeta, part, s);       // dgamma and dbeta in one launch pair
+}
+static int layernorm_bwd(const float* dy, const float* s_in, const float* mean, const float* rstd, const float* gamma, int64_t R,
+                         int D, DropoutCfg dc, float* ds, float* dh, float* dgamma, float* dbeta, char* ws, hipStream_t s,
+                         unsigned short* dh_h = nullptr) {
+    if (int rc = layernorm_bwd_rows(dy, s_in, mean, rstd, gamma, R, D, dc, ds, dh, ws, s, dh_h)) return rc;
+    return layernorm_bwd_params(R, D, dgamma, dbeta, ws, s);
 }
 
 int nr_add_layernorm_bwd_f32(const float* dy, const float* s_in, const float* mean, const float* rstd, const float* gamma, int64_t R, int64_t D, float p_drop, uint64_t seed, uint32_t site, float* ds, float* dh, float* dgamma, float* dbeta, void* ws, size_t ws_bytes, void* stream) {
@@ -642,7 +656,7 @@ size_t nr_tfm_layer_bwd_ws_bytes(int64_t N, int64_t Sq, int64_t D) {
     b += pad256((size_t)R * 4 * D);                 // dz
     b += pad256((size_t)R * 3 * D);                 // dqkv
     b += pad256((size_t)3 * D * D) + pad256((size_t)3 * D);
-    b += nr_layernorm_bwd_ws_bytes(R, D);
+    b += 2 * nr_layernorm_bwd_ws_bytes(R, D);       // one per LayerNorm (their parameter sums run on the second stream)
     size_t wmax = bwd_weight_ws(R, D, 4 * D, true);
     wmax = std::max(wmax, bwd_weight_ws(R, 4 * D, D, true));
     wmax = std::max(wmax, bwd_weight_ws(R, 3 * D, D, true));
@@ -668,6 +682,7 @@ static int tfm_layer_bwd(const float* dy, const float* x, const int64_t* mask, i
     float* dwqkv = bump(cur, 3 * DD);
     float* dbqkv = bump(cur, (size_t)3 * D);
     char* lnws = cur; cur += nr_layernorm_bwd_ws_bytes(R, D);
+    char* lnws1 = cur; cur += nr_layernorm_bwd_ws_bytes(R, D);      // LN1's own partials: LN2's are still being summed on the second stream
     char* wws = cur;
     const size_t wws_bytes = ws_bytes - (size_t)(cur - (char*)ws);
     const float* mean1 = sv->stats, *rstd1 = sv->stats + R, *mean2 = sv->stats + 2 * R, *rstd2 = sv->stats + 3 * R;
@@ -679,10 +694,11 @@ static int tfm_layer_bwd(const float* dy, const float* x, const int64_t* mask, i
     auto fork = [&](int i) { if (ss) ss->edge(ss->fork[i], s, sw); };
 
     // LN2 <- dy
-    if (int rc = layernorm_bwd(dy, sv->s2, mean2, rstd2, w->ln2_g, R, (int)D, DCP(DC(p_drop, seed, site_base + 2), nullptr, row_map), ds2,
-                               p_drop > 0.f ? dh2 : nullptr, g->dln2_g, g->dln2_b, lnws, s)) return rc;
+    if (int rc = layernorm_bwd_rows(dy, sv->s2, mean2, rstd2, w->ln2_g, R, (int)D, DCP(DC(p_drop, seed, site_base + 2), nullptr, row_map), ds2,
+                                    p_drop > 0.f ? dh2 : nullptr, lnws, s)) return rc;
     // FFN2: dW2 = dh2^T a ; dz = (dh2 W2) * gelu'(z)
     fork(0);
+    if (int rc = layernorm_bwd_params(R, (int)D, g->dln2_g, g->dln2_b, lnws, sw)) return rc;
     if (int rc = linear_bwd_weight(dh2, D, sv->a, 4 * D, R, D, 4 * D, g->dw2, g->db2, wws, wws_bytes, 0, 0, sw)) return rc;
     if (int rc = linear_bwd_input(dh2, D, w->w2, R, D, 4 * D, EPI_MUL_GELU_GRAD, sv->z, nullptr, dz, s)) return rc;
     // FFN1: dW1 = dz^T y1 ; dy1 = dz W1 + ds2 (residual)
@@ -690,10 +706,11 @@ static int tfm_layer_bwd(const float* dy, const float* x, const int64_t* mask, i
     if (int rc = linear_bwd_weight(dz, 4 * D, sv->y1, D, R, 4 * D, D, g->dw1, g->db1, wws, wws_bytes, 0, 0, sw)) return rc;
     if (int rc = linear_bwd_input(dz, 4 * D, w->w1, R, 4 * D, D, EPI_ADD_AUX, ds2, nullptr, dy1, s)) return rc;
     // LN1
-    if (int rc = layernorm_bwd(dy1, sv->s1, mean1, rstd1, w->ln1_g, R, (int)D, DCP(DC(p_drop, seed, site_base + 1), nullptr, row_map), ds1,
-                               p_drop > 0.f ? dh1 : nullptr, g->dln1_g, g->dln1_b, lnws, s)) return rc;
+    if (int rc = layernorm_bwd_rows(dy1, sv->s1, mean1, rstd1, w->ln1_g, R, (int)D, DCP(DC(p_drop, seed, site_base + 1), nullptr, row_map), ds1,
+                                    p_drop > 0.f ? dh1 : nullptr, lnws1, s)) return rc;
     // attention output projection
     fork(2);
+    if (int rc = layernorm_bwd_params(R, (int)D, g->dln1_g, g->dln1_b, lnws1, sw)) return rc;
     if (int rc = linear_bwd_weight(dh1, D, sv->ctx, D, R, D, D, g->dwo, g->dbo, wws, wws_bytes, 0, 0, sw)) return rc;
     if (int rc = linear_bwd_input(dh1, D, w->wo, R, D, D, EPI_NONE, nullptr, nullptr, dctx, s)) return rc;
     // attention core
