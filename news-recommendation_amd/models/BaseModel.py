@@ -302,7 +302,7 @@ class TwoTowerBaseModel(BaseModel):
         """score this rank's shard; results stay on the device as flat typed tensors until the end."""
         from utils.util import frozen_gc
         impr, masks, labels, preds = [], [], [], []
-        with frozen_gc():                       # thousands of batches: no full garbage collection over the datasets mid-loop
+        with frozen_gc(collect=False):          # thousands of batches: no full garbage collection over the datasets mid-loop
             for x in tqdm(loader, ncols=80, desc="Predicting", disable=self.rank != 0):
                 preds.append(self.infer(x))
                 impr.append(x["impr_index"])

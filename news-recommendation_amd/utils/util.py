@@ -200,10 +200,14 @@ class frozen_gc:
     steps of a 2.3 ms step.  Re-entrant: the outermost exit thaws."""
     depth = 0
 
+    def __init__(self, collect=True):
+        self.collect = collect                # a full collection first (tens of ms): worth it once per training run
+
     def __enter__(self):
         import gc
         if frozen_gc.depth == 0:
-            gc.collect()
+            if self.collect:
+                gc.collect()
             gc.freeze()
         frozen_gc.depth += 1
         return self
