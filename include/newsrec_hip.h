@@ -135,6 +135,12 @@ int nr_add_layernorm_bwd_noalloc_f32(const float* dy, const float* s, const floa
  *   HF BertModel computes under torch SDPA for AllBertNewsEncoder (encoder.py:74; transformers 5.15 / torch 2.10). */
 int nr_mhsa_fwd_f32(const float* qkv, const int64_t* mask, int64_t N, int64_t S, int64_t H, int64_t dh, float p_drop, uint64_t seed, uint32_t site, int mask_mode, float* ctx, float* row_max, float* row_sum, void* stream);
 int nr_mhsa_bwd_f32(const float* qkv, const int64_t* mask, const float* ctx, const float* dctx, const float* row_max, const float* row_sum, int64_t N, int64_t S, int64_t H, int64_t dh, float p_drop, uint64_t seed, uint32_t site, int mask_mode, float* dqkv, void* stream);
+/* The same core on bf16 tensors (raw 16-bit storage; S <= 32, head dim <= 64): what the bf16 build of AllBertNewsEncoder's
+ * layers calls between its bf16 GEMMs (encoder.py:62-77; parity bar 1e-2).  Head dims that are multiples of 8 run all seven
+ * products on v_mfma_f32_32x32x16_bf16 (probabilities and score gradients rounded to bf16 as operands, softmax in f32);
+ * other head dims take f32 arithmetic on the bf16 data. */
+int nr_mhsa_fwd_bf16(const void* qkv, const int64_t* mask, int64_t N, int64_t S, int64_t H, int64_t dh, float p_drop, uint64_t seed, uint32_t site, int mask_mode, void* ctx, float* row_max, float* row_sum, void* stream);
+int nr_mhsa_bwd_bf16(const void* qkv, const int64_t* mask, const void* dctx, const float* row_max, const float* row_sum, int64_t N, int64_t S, int64_t H, int64_t dh, float p_drop, uint64_t seed, uint32_t site, int mask_mode, void* dqkv, void* stream);
 
 /* ---- additive ("query") pooling — scaled_dp_attention, attention.py:6-34 -----------------------
  * out[n,:] = softmax_s(query . key[n,s,:] / sqrt(D) + (1-mask[n,s]) * -1e5) . value[n,s,:]

@@ -19,6 +19,7 @@
 // Dropout keep bits are drawn once, in the T orientation (4 consecutive keys share one Philox call
 // when S % 4 == 0), and handed to the N orientation as a 32-bit word per query through LDS.
 #include "common.h"
+#include <cstdlib>
 #include "seqops.h"
 
 namespace nr {
@@ -865,16 +866,224 @@ int mhsa_bwd_mfma2(const float* qkv, const int64_t* mask, const float* dctx, con
     return check_launch("mhsa_bwd_mfma2");
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// bf16 build (tensors bf16 in HBM, parity bar 1e-2), head dim a multiple of 8: the seven products run on
+// v_mfma_f32_32x32x16_bf16 straight from bf16 LDS tiles — 4 MFMAs for Q.K^T at dh = 64 instead of 32 on the f32 instruction.
+// Two tile layouts per operand, filled from the same 16-byte global pieces:
+//   row-major   Xr[pos][d]   (pitch DHP + 8): operand of the score-shaped products (k = d, 8 consecutive d per lane)
+//   transposed  Xt[d][pos]   (pitch 44):      A operand of the products that sum over positions
+// A product that sums over positions takes its B operand from an accumulator tile: k-slot e of MFMA kb in lane half h is
+// register 8*kb + e, i.e. position 16*kb + 8*(e>>2) + 4*h + (e&3); the A operand reads the same positions of Xt as two
+// 8-byte pieces.  Softmax, dropout and the saved statistics are the f32 code of the kernels above.
+typedef __bf16 hbf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 hbf16x4 __attribute__((ext_vector_type(4)));
+typedef float hf32x4 __attribute__((ext_vector_type(4)));
+constexpr int H16_PT = 44;                                  // pitch of the transposed tiles (elements)
+template <int DHP> struct H16 {
+    static constexpr int PR = DHP + 8;                      // pitch of the row-major tiles
+    static constexpr int RT = 32 * PR;                      // elements of a row-major tile
+    static constexpr int TT = DHP * H16_PT;                 // elements of a transposed tile
+};
+
+// [Sn rows] x [nh*dh] bf16 global segment -> per-head row-major (Rt, may be null) and transposed (Tt, may be null) tiles;
+// head stride of each is `rstride` / `tstride` elements.  dh % 8 == 0: a 16-byte piece never straddles two heads.
+template <int DHP>
+__device__ __forceinline__ void heads_in16(unsigned short* Rt, int rstride, unsigned short* Tt, int tstride, const unsigned short* __restrict__ g,
+                                           int64_t ld, int Sn, int dh, int nh, int tid, int nthr) {
+    constexpr int PR = H16<DHP>::PR;
+    const int nq = (nh * dh) >> 3;
+    const int pph = dh >> 3;                                // pieces per head
+    for (int idx = tid; idx < Sn * nq; idx += nthr) {
+        const int r = idx / nq;
+        const int q = idx - r * nq;
+        const int hh = q / pph, d0 = (q - hh * pph) << 3;
+        const uint4 u = *reinterpret_cast<const uint4*>(g + (int64_t)r * ld + (q << 3));
+        if (Rt) *reinterpret_cast<uint4*>(Rt + hh * rstride + r * PR + d0) = u;
+        if (Tt) {
+            unsigned short* t = Tt + hh * tstride + d0 * H16_PT + r;
+            const uint32_t w[4] = {u.x, u.y, u.z, u.w};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                t[(2 * k) * H16_PT] = (unsigned short)(w[k] & 0xffffu);
+                t[(2 * k + 1) * H16_PT] = (unsigned short)(w[k] >> 16);
+            }
+        }
+    }
+}
+// per-head row-major tiles [pos][d] -> [Sn rows] x [nh*dh] bf16 global segment
+template <int DHP>
+__device__ __forceinline__ void heads_out16(unsigned short* __restrict__ g, int64_t ld, const unsigned short* Rt, int rstride, int Sn, int dh,
+                                            int nh, int tid, int nthr) {
+    constexpr int PR = H16<DHP>::PR;
+    const int nq = (nh * dh) >> 3;
+    const int pph = dh >> 3;
+    for (int idx = tid; idx < Sn * nq; idx += nthr) {
+        const int r = idx / nq;
+        const int q = idx - r * nq;
+        const int hh = q / pph, d0 = (q - hh * pph) << 3;
+        *reinterpret_cast<uint4*>(g + (int64_t)r * ld + (q << 3)) = *reinterpret_cast<const uint4*>(Rt + hh * rstride + r * PR + d0);
+    }
+}
+// acc[r] = sum_d X[row(r,h)][d] * Y[l31][d] over row-major tiles (columns past dh are zero)
+template <int DHP>
+__device__ __forceinline__ f32x16 xyT16(const unsigned short* Xr, const unsigned short* Yr, int ksteps, int l31, int h) {
+    constexpr int PR = H16<DHP>::PR;
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    const unsigned short* xp = Xr + l31 * PR + 8 * h;
+    const unsigned short* yp = Yr + l31 * PR + 8 * h;
+#pragma unroll
+    for (int ks = 0; ks < DHP / 16; ++ks) {
+        if (ks < ksteps) {
+            const hbf16x8 fa = *reinterpret_cast<const hbf16x8*>(xp + 16 * ks);
+            const hbf16x8 fb = *reinterpret_cast<const hbf16x8*>(yp + 16 * ks);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb, acc, 0, 0, 0);
+        }
+    }
+    return acc;
+}
+// eight accumulator registers 8*kb .. 8*kb+7 as the bf16 B operand of MFMA kb
+__device__ __forceinline__ hbf16x8 pack_regs16(const f32x16& t, int kb) {
+    hbf16x8 o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = (__bf16)t[8 * kb + e];
+    return o;
+}
+// out[r] = sum over positions k of Zt[dt*32 + row(r,h)][k] * tile[k][l31]  (tile = an accumulator tile whose ROW index is k)
+__device__ __forceinline__ f32x16 zT16(const unsigned short* Zt, const f32x16& tile, int dt, int l31, int h) {
+    f32x16 o;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[r] = 0.f;
+    const unsigned short* zp = Zt + (dt * 32 + l31) * H16_PT + 4 * h;
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+        const uint2 lo = *reinterpret_cast<const uint2*>(zp + 16 * kb);
+        const uint2 hi = *reinterpret_cast<const uint2*>(zp + 16 * kb + 8);
+        const uint4 a4 = make_uint4(lo.x, lo.y, hi.x, hi.y);
+        const hbf16x8 fa = __builtin_bit_cast(hbf16x8, a4);
+        o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, pack_regs16(tile, kb), o, 0, 0, 0);
+    }
+    return o;
+}
+// result rows = feature d (dt*32 + row(r,h)), col = position l31 -> row-major bf16 tile [pos][d]: registers 4g .. 4g+3 are
+// four consecutive features = one 8-byte store
+template <int DHP>
+__device__ __forceinline__ void put16(unsigned short* Tr, const f32x16& o, int dt, int l31, int h) {
+    constexpr int PR = H16<DHP>::PR;
+#pragma unroll
+    for (int gq = 0; gq < 4; ++gq) {
+        const uint2 v = make_uint2(apack2(o[4 * gq], o[4 * gq + 1]), apack2(o[4 * gq + 2], o[4 * gq + 3]));
+        *reinterpret_cast<uint2*>(Tr + l31 * PR + dt * 32 + 8 * gq + 4 * h) = v;
+    }
+}
+
+template <int DHP, int NHG>
+__global__ __launch_bounds__(64 * NHG) void mhsa_fwd_mfma16_kernel(const unsigned short* __restrict__ qkv, const int64_t* __restrict__ mask,
+                                                               unsigned short* __restrict__ ctx, float* __restrict__ row_max,
+                                                               float* __restrict__ row_sum, int S, int H, int dh, DropoutCfg dc) {
+    constexpr int RT = H16<DHP>::RT, TT = H16<DHP>::TT, NTHR = 64 * NHG;
+    constexpr int DT = DHP / 32;
+    extern __shared__ __attribute__((aligned(16))) unsigned short hsm16[];
+    unsigned short* Qr = hsm16;                       // [NHG][RT]  (reused for the output tiles)
+    unsigned short* Kr = Qr + NHG * RT;
+    unsigned short* Vt = Kr + NHG * RT;               // [NHG][TT]
+    float* Mk = reinterpret_cast<float*>(Vt + NHG * TT);
+    const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63, l31 = lane & 31, h = lane >> 5;
+    const int groups = (H + NHG - 1) / NHG;
+    const int n = blockIdx.x / groups, gidx = blockIdx.x - n * groups;
+    const int hd0 = gidx * NHG, nh = min(NHG, H - hd0), hd = hd0 + w;
+    const bool active = w < nh;
+    const int A = H * dh;
+    const int64_t ld = 3 * (int64_t)A;
+    const int64_t row0 = dc.offs ? (int64_t)dc.offs[n] : (int64_t)n * S;
+    const int Sn = dc.offs ? dc.offs[n + 1] - dc.offs[n] : S;
+    if (Sn == 0) return;
+    // zero everything the MFMAs read (rows / positions past Sn, columns past dh), then fill
+    {
+        uint4* z = reinterpret_cast<uint4*>(hsm16);
+        const int n16 = (NHG * (2 * RT + TT)) >> 3;
+        for (int i = tid; i < n16; i += NTHR) z[i] = make_uint4(0u, 0u, 0u, 0u);
+    }
+    if (tid < 32) Mk[tid] = tid < Sn ? (mask[(int64_t)n * S + tid] ? 0.f : dc.mask_fill) : -INFINITY;
+    __syncthreads();
+    const unsigned short* base = qkv + row0 * ld + hd0 * dh;
+    heads_in16<DHP>(Qr, RT, nullptr, 0, base, ld, Sn, dh, nh, tid, NTHR);
+    heads_in16<DHP>(Kr, RT, nullptr, 0, base + A, ld, Sn, dh, nh, tid, NTHR);
+    heads_in16<DHP>(nullptr, 0, Vt, TT, base + 2 * A, ld, Sn, dh, nh, tid, NTHR);
+    __syncthreads();
+    unsigned short* Qs = Qr + w * RT; const unsigned short* Ks = Kr + w * RT; const unsigned short* Vs = Vt + w * TT;
+    f32x16 st;
+    if (active) {
+        const float sq = sqrtf((float)dh), rsq = 1.0f / sq;
+        st = xyT16<DHP>(Ks, Qs, (dh + 15) >> 4, l31, h);       // row = key, col = query (this lane's query = l31)
+        float m = -INFINITY;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float x = div_by(st[r], sq, rsq) + Mk[krow(r, h)];
+            st[r] = x;
+            m = fmaxf(m, x);
+        }
+        m = fmaxf(m, __shfl_xor(m, 32, 64));
+        if (m == -INFINITY) m = 0.f;
+        float sum = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float e = expf(st[r] - m);
+            st[r] = e;
+            sum += e;
+        }
+        sum += __shfl_xor(sum, 32, 64);
+        if (sum == 0.f) sum = 1.f;
+        const int64_t qrow = ((int64_t)n * H + hd) * S + l31;
+        if (row_max && h == 0 && l31 < Sn) { row_max[qrow] = m; row_sum[qrow] = sum; }
+        unsigned bits = 0xFFFFu;
+        float scale = 1.f;
+        if (dc.p > 0.f) { bits = keep_bits16(dc, drop_threshold(dc.p), qrow, S, h); scale = 1.0f / (1.0f - dc.p); }
+        const float rsum = 1.0f / sum;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            float p = div_by(st[r], sum, rsum);
+            if (dc.p > 0.f) p = ((bits >> r) & 1u) ? p * scale : 0.f;
+            st[r] = p;
+        }
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) {
+            const f32x16 o = zT16(Vs, st, dt, l31, h);             // O^T[d][query]
+            put16<DHP>(Qs, o, dt, l31, h);                          // this wave's own Q tile: nobody else reads it
+        }
+    }
+    __syncthreads();
+    heads_out16<DHP>(ctx + row0 * A + hd0 * dh, A, Qr, RT, Sn, dh, nh, tid, NTHR);
+}
+
 // bf16 tensors in HBM (raw 16-bit storage), f32 tiles and arithmetic; 16-byte pieces need A % 8 == 0 and aligned bases
 static bool vec_ok_h(const void* a, const void* b, int H, int dh) {
     const int A = H * dh;
     return (A % 8 == 0) && (((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b)) & 15) == 0) && (((dh <= 32 ? 4 : 2) * dh) % 8 == 0);
+}
+// the bf16-MFMA kernels take head dims that are multiples of 8 on 16-byte aligned tensors (NR_ATTN_BF16_MFMA=0: f32 arithmetic)
+static bool mfma16_ok(const void* a, const void* b, int H, int dh) {
+    static const bool on = !(getenv("NR_ATTN_BF16_MFMA") && atoi(getenv("NR_ATTN_BF16_MFMA")) == 0);
+    return on && dh % 8 == 0 && dh <= 64 && (((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b)) & 15) == 0);
 }
 int mhsa_fwd_mfma_h(const unsigned short* qkv, const int64_t* mask, unsigned short* ctx, float* row_max, float* row_sum, int64_t N, int S,
                     int H, int dh, DropoutCfg dc, hipStream_t s) {
     if (N == 0) return NR_OK;
     NR_UNSUPPORTED(!mhsa_mfma_supported(S, dh), "mhsa (bf16 tensors): S=%d, head dim %d outside the matrix-core kernel (S <= 32, dh <= 64)", S, dh);
     ProfScope prof(FAM_ATTN, s, 4.0 * N * H * S * S * dh);
+    if (mfma16_ok(qkv, ctx, H, dh)) {
+        const int dhp = dh <= 32 ? 32 : 64, hpg = 2;
+        const dim3 grid((unsigned)(N * ((H + hpg - 1) / hpg)));
+        if (dhp == 32) {
+            const size_t lds = (size_t)hpg * (2 * H16<32>::RT + H16<32>::TT) * 2 + 128;
+            hipLaunchKernelGGL((mhsa_fwd_mfma16_kernel<32, 2>), grid, dim3(128), lds, s, qkv, mask, ctx, row_max, row_sum, S, H, dh, dc);
+        } else {
+            const size_t lds = (size_t)hpg * (2 * H16<64>::RT + H16<64>::TT) * 2 + 128;
+            hipLaunchKernelGGL((mhsa_fwd_mfma16_kernel<64, 2>), grid, dim3(128), lds, s, qkv, mask, ctx, row_max, row_sum, S, H, dh, dc);
+        }
+        return check_launch("mhsa_fwd_mfma16");
+    }
     return launch_fwd<unsigned short>(qkv, mask, ctx, row_max, row_sum, N, S, H, dh, dc, vec_ok_h(qkv, ctx, H, dh) ? 1 : 0, s);
 }
 int mhsa_bwd_mfma_h(const unsigned short* qkv, const int64_t* mask, const unsigned short* dctx, const float* row_max, const float* row_sum,

@@ -428,6 +428,20 @@ int nr_mhsa_bwd_f32(const float* qkv, const int64_t* mask, const float* ctx, con
     return mhsa_bwd(qkv, mask, ctx, dctx, row_max, row_sum, dqkv, N, (int)Sq, (int)H, (int)dh, DCA(p_drop, seed, site, mask_mode), S(stream));
 }
 
+// the same core on bf16 tensors (the bf16 build of the BERT-sized layers keeps qkv / ctx and their gradients as bf16 in HBM)
+int nr_mhsa_fwd_bf16(const void* qkv, const int64_t* mask, int64_t N, int64_t Sq, int64_t H, int64_t dh, float p_drop, uint64_t seed, uint32_t site, int mask_mode, void* ctx, float* row_max, float* row_sum, void* stream) {
+    NR_CHECK_ARG(N >= 0 && Sq > 0 && H > 0 && dh > 0, "mhsa_fwd_bf16: bad sizes");
+    NR_CHECK_ARG(N == 0 || (qkv && mask && ctx), "mhsa_fwd_bf16: null pointer");
+    NR_CHECK_ARG((row_max == nullptr) == (row_sum == nullptr), "mhsa_fwd_bf16: row_max/row_sum must both be given or both NULL");
+    return mhsa_fwd_mfma_h((const unsigned short*)qkv, mask, (unsigned short*)ctx, row_max, row_sum, N, (int)Sq, (int)H, (int)dh, DCA(p_drop, seed, site, mask_mode), S(stream));
+}
+
+int nr_mhsa_bwd_bf16(const void* qkv, const int64_t* mask, const void* dctx, const float* row_max, const float* row_sum, int64_t N, int64_t Sq, int64_t H, int64_t dh, float p_drop, uint64_t seed, uint32_t site, int mask_mode, void* dqkv, void* stream) {
+    NR_CHECK_ARG(N >= 0 && Sq > 0 && H > 0 && dh > 0, "mhsa_bwd_bf16: bad sizes");
+    NR_CHECK_ARG(N == 0 || (qkv && mask && dctx && row_max && row_sum && dqkv), "mhsa_bwd_bf16: null pointer");
+    return mhsa_bwd_mfma_h((const unsigned short*)qkv, mask, (const unsigned short*)dctx, row_max, row_sum, (unsigned short*)dqkv, N, (int)Sq, (int)H, (int)dh, DCA(p_drop, seed, site, mask_mode), S(stream));
+}
+
 int nr_query_pool_fwd_f32(const float* key, const float* value, const float* table, const int64_t* idx, int64_t table_rows, const float* query, const int64_t* mask, int64_t nseq, int64_t Sq, int64_t D, float* out, float* prob, void* stream) {
     NR_CHECK_ARG(nseq >= 0 && Sq > 0 && D > 0, "query_pool_fwd: bad sizes");
     NR_CHECK_ARG(nseq == 0 || (query && out), "query_pool_fwd: null pointer");

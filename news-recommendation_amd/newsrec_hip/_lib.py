@@ -70,6 +70,8 @@ _SIGS = {
     "nr_add_layernorm_bwd_noalloc_f32": (c_int, [c_fp, c_fp, c_fp, c_fp, c_fp, c_i64, c_i64, c_f, c_u64, c_u32,
                                                  c_fp, c_fp, c_fp, c_fp, c_fp]),
     "nr_mhsa_fwd_f32": (c_int, [c_fp, c_fp, c_i64, c_i64, c_i64, c_i64, c_f, c_u64, c_u32, c_int, c_fp, c_fp, c_fp, c_fp]),
+    "nr_mhsa_fwd_bf16": (c_int, [c_fp, c_fp, c_i64, c_i64, c_i64, c_i64, c_f, c_u64, c_u32, c_int, c_fp, c_fp, c_fp, c_fp]),
+    "nr_mhsa_bwd_bf16": (c_int, [c_fp, c_fp, c_fp, c_fp, c_fp, c_i64, c_i64, c_i64, c_i64, c_f, c_u64, c_u32, c_int, c_fp, c_fp]),
     "nr_mhsa_bwd_f32": (c_int, [c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_i64, c_i64, c_i64, c_i64, c_f, c_u64, c_u32, c_int,
                                 c_fp, c_fp]),
     "nr_query_pool_fwd_f32": (c_int, [c_fp, c_fp, c_fp, c_fp, c_i64, c_fp, c_fp, c_i64, c_i64, c_i64, c_fp, c_fp, c_fp]),

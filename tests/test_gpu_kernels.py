@@ -405,6 +405,47 @@ def test_mhsa_minus_inf_mask(ops, N, S, H, dh, p):
     assert relerr(dq, qr.grad) < 2e-5
 
 
+@pytest.mark.parametrize("N,S,H,dh", [(440, 32, 12, 64), (9, 32, 4, 32), (7, 20, 3, 40), (5, 9, 2, 8), (6, 32, 5, 24), (4, 17, 3, 25)])
+@pytest.mark.parametrize("p", [0.0, 0.1])
+def test_mhsa_bf16_tensors(ops, N, S, H, dh, p):
+    """nr_mhsa_{fwd,bwd}_bf16 (the attention of the bf16 build): bf16 tensors in HBM, head dims that are multiples of 8 on
+    the bf16 matrix instruction (the last shape takes the f32-arithmetic kernel).  Reference: the f32 attention of the
+    bf16-rounded inputs; bar = the bf16 build's 1e-2 (operands P and dS are rounded to bf16: ~4e-3 expected)."""
+    g = G(82)
+    A = H * dh
+    qkv = (torch.randn(N * S, 3 * A, generator=g)).bfloat16()
+    lens = torch.randint(1, S + 1, (N,), generator=g)
+    lens[0] = S
+    mask = (torch.arange(S)[None] < lens[:, None]).long()
+    if N > 2:
+        mask[2] = 0                                      # no valid key: zero context, zero gradients (mask_mode 1)
+    dctx = torch.randn(N * S, A, generator=g).bfloat16()
+    seed, site = 11, 4
+    keep = keep_mask((N, H, S, S), p, seed, site) if p > 0 else None
+    qr = qkv.float().requires_grad_(True)
+    q, k, v = [t.reshape(N, S, H, dh).permute(0, 2, 1, 3) for t in qr.reshape(N, S, 3, A).unbind(2)]
+    sc = (torch.matmul(q, k.transpose(-1, -2)) / math.sqrt(dh)).masked_fill(mask[:, None, None, :] == 0, float("-inf"))
+    pr = torch.nan_to_num(torch.softmax(sc, -1), nan=0.0)
+    ref = torch.matmul(O._drop(pr, keep, p), v).permute(0, 2, 1, 3).reshape(N * S, A)
+    ref.backward(dctx.float())
+    L = ops.lib()
+    st = torch.cuda.current_stream().cuda_stream
+    qg, mg, dcg = qkv.cuda(), mask.cuda(), dctx.cuda()
+    ctx = torch.empty(N * S, A, dtype=torch.bfloat16, device="cuda")
+    rmax = torch.empty(N, H, S, device="cuda"); rsum = torch.empty(N, H, S, device="cuda")
+    ops.check(L.nr_mhsa_fwd_bf16(qg.data_ptr(), mg.data_ptr(), N, S, H, dh, p, seed, site, 1, ctx.data_ptr(), rmax.data_ptr(),
+                                 rsum.data_ptr(), st))
+    live = mask.bool().reshape(-1).cuda()                 # rows of padded positions are not part of the contract
+    assert torch.isfinite(ctx.float()).all()
+    assert relerr(ctx.float()[live], ref.detach().cuda()[live]) < 1e-2
+    dq = torch.empty(N * S, 3 * A, dtype=torch.bfloat16, device="cuda")
+    ops.check(L.nr_mhsa_bwd_bf16(qg.data_ptr(), mg.data_ptr(), dcg.data_ptr(), rmax.data_ptr(), rsum.data_ptr(), N, S, H, dh, p, seed, site, 1,
+                                 dq.data_ptr(), st))
+    assert torch.isfinite(dq.float()).all()
+    # the reference propagates dctx of padded query rows too; the kernels see the same rows (dense layout), so compare all
+    assert relerr(dq.float(), qr.grad.cuda()) < 1e-2
+
+
 def test_mhsa_masked_quantisation_exact(ops):
     """integer-valued inputs make every dot product exact, so the kernel must reproduce the
     reference's fl32(score/sqrt(dh) - 1e5) quantisation on a fully masked row BIT FOR BIT-ish."""
