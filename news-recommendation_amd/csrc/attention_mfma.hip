@@ -1057,6 +1057,130 @@ __global__ __launch_bounds__(64 * NHG) void mhsa_fwd_mfma16_kernel(const unsigne
     heads_out16<DHP>(ctx + row0 * A + hd0 * dh, A, Qr, RT, Sn, dh, nh, tid, NTHR);
 }
 
+template <int DHP, int NHG>
+__global__ __launch_bounds__(64 * NHG) void mhsa_bwd_mfma16_kernel(const unsigned short* __restrict__ qkv, const int64_t* __restrict__ mask,
+                                                               const unsigned short* __restrict__ dctx, const float* __restrict__ row_max,
+                                                               const float* __restrict__ row_sum, unsigned short* __restrict__ dqkv,
+                                                               int S, int H, int dh, DropoutCfg dc) {
+    constexpr int RT = H16<DHP>::RT, TT = H16<DHP>::TT, NTHR = 64 * NHG;
+    constexpr int DT = DHP / 32;
+    extern __shared__ __attribute__((aligned(16))) unsigned short hsm16[];
+    unsigned short* Qr = hsm16;                       // row-major [NHG][RT] each
+    unsigned short* Kr = Qr + NHG * RT;
+    unsigned short* Vr = Kr + NHG * RT;
+    unsigned short* Gr = Vr + NHG * RT;
+    unsigned short* Qt = Gr + NHG * RT;               // transposed [NHG][TT] each
+    unsigned short* Kt = Qt + NHG * TT;
+    unsigned short* Gt = Kt + NHG * TT;
+    float* St = reinterpret_cast<float*>(Gt + NHG * TT);   // [NHG][4][32]: max, 1/sum, D, key-mask term ; then [NHG][32] keep words
+    const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63, l31 = lane & 31, h = lane >> 5;
+    const int groups = (H + NHG - 1) / NHG;
+    const int n = blockIdx.x / groups, gidx = blockIdx.x - n * groups;
+    const int hd0 = gidx * NHG, nh = min(NHG, H - hd0), hd = hd0 + w;
+    const bool active = w < nh;
+    const int A = H * dh;
+    const int64_t ld = 3 * (int64_t)A;
+    const int64_t row0 = dc.offs ? (int64_t)dc.offs[n] : (int64_t)n * S;
+    const int Sn = dc.offs ? dc.offs[n + 1] - dc.offs[n] : S;
+    if (Sn == 0) return;
+    {
+        uint4* z = reinterpret_cast<uint4*>(hsm16);
+        const int n16 = (NHG * (4 * RT + 3 * TT)) >> 3;
+        for (int i = tid; i < n16; i += NTHR) z[i] = make_uint4(0u, 0u, 0u, 0u);
+    }
+    float* Ms = St + w * 128; float* Rl = Ms + 32; float* Dsh = Ms + 64; float* Mk = Ms + 96;
+    unsigned* Kb = reinterpret_cast<unsigned*>(St + NHG * 128) + w * 32;
+    const int64_t qrow0 = ((int64_t)n * H + hd) * S;
+    if (active && lane < 32) {
+        const bool ok = lane < Sn;
+        Ms[lane] = ok ? row_max[qrow0 + lane] : 0.f;
+        Rl[lane] = ok ? 1.0f / row_sum[qrow0 + lane] : 1.f;
+        Mk[lane] = ok ? (mask[(int64_t)n * S + lane] ? 0.f : dc.mask_fill) : -INFINITY;
+    }
+    __syncthreads();
+    const unsigned short* base = qkv + row0 * ld + hd0 * dh;
+    heads_in16<DHP>(Qr, RT, Qt, TT, base, ld, Sn, dh, nh, tid, NTHR);
+    heads_in16<DHP>(Kr, RT, Kt, TT, base + A, ld, Sn, dh, nh, tid, NTHR);
+    heads_in16<DHP>(Vr, RT, nullptr, 0, base + 2 * A, ld, Sn, dh, nh, tid, NTHR);
+    heads_in16<DHP>(Gr, RT, Gt, TT, dctx + row0 * A + hd0 * dh, A, Sn, dh, nh, tid, NTHR);
+    __syncthreads();
+    unsigned short* Qs = Qr + w * RT; unsigned short* Ks = Kr + w * RT; unsigned short* Vs = Vr + w * RT; const unsigned short* Gs = Gr + w * RT;
+    const unsigned short* Qts = Qt + w * TT; const unsigned short* Kts = Kt + w * TT; const unsigned short* Gts = Gt + w * TT;
+    const int ksteps = (dh + 15) >> 4;
+    const float sq = sqrtf((float)dh), rsq = 1.0f / sq;
+    const float scale = dc.p > 0.f ? 1.0f / (1.0f - dc.p) : 1.0f;
+    if (active) {
+        f32x16 dq[DT], dk[DT], dv[DT];
+        {
+            // ---------------- T orientation: row = key, col = query (lane's query = l31)
+            f32x16 st = xyT16<DHP>(Ks, Qs, ksteps, l31, h);
+            const f32x16 dpt = xyT16<DHP>(Vs, Gs, ksteps, l31, h);      // dPd^T[key][query] = V[key].dO[query]
+            const float m = Ms[l31], rsum = Rl[l31];
+            unsigned bits = 0xFFFFu;
+            if (dc.p > 0.f) {
+                bits = keep_bits16(dc, drop_threshold(dc.p), qrow0 + l31, S, h);
+                unsigned word = 0;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) word |= ((bits >> r) & 1u) << krow(r, h);
+                word |= __shfl_xor(word, 32, 64);
+                if (h == 0) Kb[l31] = word;
+            }
+            float pr[16];
+            float dpart = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float x = div_by(st[r], sq, rsq) + Mk[krow(r, h)];
+                const float p = expf(x - m) * rsum;
+                const float pd = (dc.p > 0.f) ? (((bits >> r) & 1u) ? p * scale : 0.f) : p;
+                pr[r] = p;
+                st[r] = pd * dpt[r];                               // Pd * dPd
+                dpart += st[r];
+            }
+            const float D = dpart + __shfl_xor(dpart, 32, 64);
+            if (h == 0) Dsh[l31] = D;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) st[r] = div_by(st[r] - pr[r] * D, sq, rsq);      // dS^T
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) dq[dt] = zT16(Kts, st, dt, l31, h);           // dQ^T[d][query]
+        }
+        // Dsh / Kb were written by this wave's own lanes: LDS operations of a wave complete in order
+        {
+            // ---------------- N orientation: row = query, col = key (lane's key = l31)
+            f32x16 ds = xyT16<DHP>(Qs, Ks, ksteps, l31, h);
+            const f32x16 dpn = xyT16<DHP>(Gs, Vs, ksteps, l31, h);
+            f32x16 pdn;
+            const float mk = Mk[l31];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int i = krow(r, h);
+                const float x = div_by(ds[r], sq, rsq) + mk;
+                const float p = expf(x - Ms[i]) * Rl[i];
+                float pd = p;
+                if (dc.p > 0.f) pd = ((Kb[i] >> l31) & 1u) ? p * scale : 0.f;
+                pdn[r] = pd;
+                ds[r] = div_by(pd * dpn[r] - p * Dsh[i], sq, rsq);           // dS[query][key]
+            }
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) {
+                dk[dt] = zT16(Qts, ds, dt, l31, h);                // dK^T[d][key]
+                dv[dt] = zT16(Gts, pdn, dt, l31, h);               // dV^T[d][key]
+            }
+        }
+        // every read of this head's tiles is done (they are this wave's alone): the row-major tiles become the staging area
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) {
+            put16<DHP>(Qs, dq[dt], dt, l31, h);
+            put16<DHP>(Ks, dk[dt], dt, l31, h);
+            put16<DHP>(Vs, dv[dt], dt, l31, h);
+        }
+    }
+    __syncthreads();
+    unsigned short* dbase = dqkv + row0 * ld + hd0 * dh;
+    heads_out16<DHP>(dbase, ld, Qr, RT, Sn, dh, nh, tid, NTHR);
+    heads_out16<DHP>(dbase + A, ld, Kr, RT, Sn, dh, nh, tid, NTHR);
+    heads_out16<DHP>(dbase + 2 * A, ld, Vr, RT, Sn, dh, nh, tid, NTHR);
+}
+
 // bf16 tensors in HBM (raw 16-bit storage), f32 tiles and arithmetic; 16-byte pieces need A % 8 == 0 and aligned bases
 static bool vec_ok_h(const void* a, const void* b, int H, int dh) {
     const int A = H * dh;
@@ -1091,6 +1215,24 @@ int mhsa_bwd_mfma_h(const unsigned short* qkv, const int64_t* mask, const unsign
     if (N == 0) return NR_OK;
     NR_UNSUPPORTED(!mhsa_mfma_supported(S, dh), "mhsa bwd (bf16 tensors): S=%d, head dim %d outside the matrix-core kernel (S <= 32, dh <= 64)", S, dh);
     ProfScope prof(FAM_ATTN, s, 10.0 * N * H * S * S * dh);
+    if (mfma16_ok(qkv, dctx, H, dh) && mfma16_ok(dqkv, dqkv, H, dh)) {
+        const int dhp = dh <= 32 ? 32 : 64, hpg = 2;
+        const dim3 grid((unsigned)(N * ((H + hpg - 1) / hpg)));
+        static bool once = false;
+        if (!once) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mhsa_bwd_mfma16_kernel<32, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mhsa_bwd_mfma16_kernel<64, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            once = true;
+        }
+        if (dhp == 32) {
+            const size_t lds = (size_t)hpg * (4 * H16<32>::RT + 3 * H16<32>::TT) * 2 + (size_t)hpg * 160 * 4;
+            hipLaunchKernelGGL((mhsa_bwd_mfma16_kernel<32, 2>), grid, dim3(128), lds, s, qkv, mask, dctx, row_max, row_sum, dqkv, S, H, dh, dc);
+        } else {
+            const size_t lds = (size_t)hpg * (4 * H16<64>::RT + 3 * H16<64>::TT) * 2 + (size_t)hpg * 160 * 4;
+            hipLaunchKernelGGL((mhsa_bwd_mfma16_kernel<64, 2>), grid, dim3(128), lds, s, qkv, mask, dctx, row_max, row_sum, dqkv, S, H, dh, dc);
+        }
+        return check_launch("mhsa_bwd_mfma16");
+    }
     return launch_bwd<unsigned short>(qkv, mask, dctx, row_max, row_sum, dqkv, N, S, H, dh, dc, (vec_ok_h(qkv, dctx, H, dh) && vec_ok_h(dqkv, dqkv, H, dh)) ? 1 : 0, s);
 }
 
