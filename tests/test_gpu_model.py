@@ -171,6 +171,35 @@ def _packed_case(N, S, D, H, seed, with_empty):
     return layer, x, lens, mask, dy
 
 
+@pytest.mark.parametrize("bf16", [False, True])
+def test_second_stream_changes_nothing(bf16):
+    """the layer backward with its weight-gradient products on the library's second stream (the default) against the same
+    call with everything on the caller's stream (ops.set_side_stream(False)): same kernels, same order per buffer, so
+    every gradient is bit-identical — and stays so when the call is repeated while the side stream is still busy"""
+    from newsrec_hip import ops
+    N, S, D, H = (440, 32, 768, 12) if bf16 else (700, 32, 300, 12)
+    layer, x, lens, mask, dy = _packed_case(N, S, D, H, 77, with_empty=False)
+    layer = layer.cuda().train()
+    if bf16:
+        ops.set_gemm_compute("bf16")
+    try:
+        runs = []
+        for on in (False, True, True):
+            ops.set_side_stream(on)
+            layer.zero_grad()
+            xg = x.cuda().requires_grad_(True)
+            out = ops.tfm_layer(xg, mask.cuda(), H, layer.kernel_params(), 0.1, 0x5EED, 3)
+            out.backward(dy.cuda())
+            runs.append((out.detach().clone(), xg.grad.clone(), {n: p_.grad.clone() for n, p_ in layer.named_parameters()}))
+        for out, dx, grads in runs[1:]:
+            assert torch.equal(out, runs[0][0]) and torch.equal(dx, runs[0][1])
+            for n in grads:
+                assert torch.equal(grads[n], runs[0][2][n]), n
+    finally:
+        ops.set_side_stream(True)
+        ops.set_gemm_compute("fp32")
+
+
 @pytest.mark.parametrize("gemm", ["fp32-mfma", "fp32"])
 @pytest.mark.parametrize("N,S,D,H", [(64, 32, 300, 12), (1760, 32, 300, 12), (40, 32, 768, 12), (9, 17, 24, 4)])
 def test_packed_layer_equals_padded_layer(N, S, D, H, gemm):
