@@ -393,9 +393,8 @@ __global__ __launch_bounds__(64 * NHG) void mhsa_fwd_mfma_kernel(const T* __rest
             if (dc.p > 0.f) p = ((bits >> r) & 1u) ? p * scale : 0.f;
             st[r] = p;
         }
-    }
-    __syncthreads();                                           // all waves are done reading the Q tiles
-    if (active) {
+        // the output goes into this wave's own Q tile, which only this wave reads: no barrier (a wave's LDS operations
+        // complete in order)
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt) {
             const f32x16 o = zT_tile(Vs, st, dt, l31, h, LD);     // O^T[d][query]
@@ -488,9 +487,7 @@ __global__ __launch_bounds__(64 * NHG) void mhsa_bwd_mfma_kernel(const T* __rest
         for (int r = 0; r < 16; ++r) st[r] = div_by(st[r] - pr[r] * D, sq, rsq);      // dS^T
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt) dq[dt] = zT_tile(Ks, st, dt, l31, h, LD);   // dQ^T[d][query], kept in registers
-    }
-    __syncthreads();                                           // Dsh / Kb visible (same wave, but keep it simple)
-    if (active) {
+        // Dsh / Kb were written by this wave's own lanes and are read by it alone: no barrier
         // ---------------- N orientation: row = query, col = key (lane's key = l31)
         ds = tile_xyT(Qs, Ks, dh, l31, h);
         const f32x16 dpn = tile_xyT(Gs, Vs, dh, l31, h);
@@ -505,10 +502,7 @@ __global__ __launch_bounds__(64 * NHG) void mhsa_bwd_mfma_kernel(const T* __rest
             pdn[r] = pd;
             ds[r] = div_by(pd * dpn[r] - p * Dsh[i], sq, rsq);           // dS[query][key]
         }
-    }
-    __syncthreads();                                           // K and V tiles are dead: reuse them as staging
-    T* dbase = dqkv + row0 * ld + hd0 * dh;
-    if (active) {
+        // this head's K and V tiles are dead and were this wave's alone: they become the staging area
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt) {
             put_T(Ks, dq[dt], dt, l31, h, LD, dh);
@@ -517,6 +511,7 @@ __global__ __launch_bounds__(64 * NHG) void mhsa_bwd_mfma_kernel(const T* __rest
         }
     }
     __syncthreads();
+    T* dbase = dqkv + row0 * ld + hd0 * dh;
     heads_out<DHP>(dbase, ld, Kt, Sn, dh, nh, tid, vec, 64 * NHG);
     heads_out<DHP>(dbase + A, ld, Vt, Sn, dh, nh, tid, vec, 64 * NHG);
     __syncthreads();
