@@ -80,7 +80,9 @@ int nr_get_gemm_compute(void);
 int nr_index_status(int* out_flag, void* stream);
 int nr_gather_rows_f32(const float* table, int64_t V, int64_t E, const int64_t* ids, int64_t n, float* out, int* oob_flag, void* stream);
 /* embedding backward (autograd of encoder.py:52): grad_table[ids[r],:] += grad_rows[r,:], rows with
- * ids[r] == padding_idx skipped (BERT word_embeddings has padding_idx = 0).  grad_table is NOT zeroed. */
+ * ids[r] == padding_idx skipped (BERT word_embeddings has padding_idx = 0).  grad_table is NOT zeroed.  Rows of a 128-row
+ * window that share an id are summed in LDS first ([CLS] / [SEP] sit in every title), so E <= 1920 (NR_ERR_UNSUPPORTED above);
+ * the order of the floating-point additions is not fixed from run to run (atomics), as in torch's index_add. */
 int nr_scatter_add_rows_f32(const float* grad_rows, const int64_t* ids, int64_t n, int64_t E, int64_t V, int64_t padding_idx, float* grad_table, void* stream);
 
 /* ---- dense layers on f32 MFMA — nn.Linear / nn.Conv1d call sites --------------------------------
