@@ -426,9 +426,31 @@ def main():
     if world > 1:
         ar_ms = sum(a.elapsed_time(b) for a, b in ar_events) / max(len(ar_events), 1)
         nbytes = net.flat.numel() * 4
+        # each of the two collectives alone (what sync() issues: the dense parameters, started during the backward at the
+        # token table's scatter-add, and the table gradient), 10 repetitions between events on rank 0
+        pieces = {}
+        for name, buf in (("dense_params", net.flat_early), ("token_table", net.flat_late)):
+            if buf.numel() == 0:
+                continue
+            scratch = torch.zeros_like(buf)
+            for _ in range(2):
+                all_reduce_(scratch)
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(10):
+                all_reduce_(scratch)
+            e1.record()
+            torch.cuda.synchronize()
+            ms = e0.elapsed_time(e1) / 10
+            pieces[name] = {"bytes": buf.numel() * 4, "ms": round(ms, 4), "algbw_GB/s": round(buf.numel() * 4 / (ms * 1e-3) / 1e9, 1) if ms > 0 else None}
         allreduce = {"ms_per_step": round(ar_ms, 4), "frac_of_step": round(ar_ms / ms_per_step, 4), "bytes": nbytes,
                      "algbw_GB/s": round(nbytes / (ar_ms * 1e-3) / 1e9, 1) if ar_ms > 0 else None,
-                     "backend": dist.get_backend(), "note": "events around FlatGradSync.sync (one flat all-reduce + 1/N scale) on rank 0"}
+                     "pieces_alone": pieces,
+                     "backend": dist.get_backend(),
+                     "note": "ms_per_step = events around FlatGradSync.sync on rank 0 in the one-kernel-at-a-time leg: the exposed part "
+                             "(table all-reduce + wait for the dense one, which was started at the scatter-add + 1/N scale); "
+                             "pieces_alone = each collective by itself"}
     fam = {}
     for name, idx in (("gemm", 0), ("gather", 1), ("attention", 2), ("layernorm", 3), ("pool", 4), ("score", 5), ("misc", 6), ("scatter_add", 7),
                       ("gemm_split", 8)):

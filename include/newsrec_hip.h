@@ -52,8 +52,14 @@ int nr_prof_read(int family, double* ms, int64_t* launches, double* work);
  * mode 2 (default): fp32 results on the bf16 matrix pipe.  Each fp32 operand is split on its way into LDS into three
  * bf16 pieces (a = a0 + a1 + a2, all 24 significand bits) and a*b is accumulated in fp32 from the six piece products of
  * weight >= 2^-16; the dropped ones are below fp32's own rounding of the product, so the result has fp32 accuracy
- * (the 1e-5 parity bar, same tests) at 1.3-1.6x the rate of the fp32 instruction.  Products too small to fill the chip
+ * (the 1e-5 parity bar, same tests; tests/test_gpu_gemm_fp64.py holds it against float64 next to mode 0 on operands whose
+ * rows and columns span 1e-6 .. 1e4) at 1.3-1.6x the rate of the fp32 instruction.  Products too small to fill the chip
  * with the kernel's 16 384-element tiles run as in mode 0.
+ * PRECONDITION of mode 2: finite operands with |a| <= 3.38e38 (the largest finite bf16).  a = +-inf, or an |a| that
+ * rounds up to inf in bf16, makes the residual piece inf - inf = NaN and the whole dot product NaN where mode 0 would
+ * give +-inf or a finite value; NaN operands give NaN in both modes.  Operands below about 1e-33 in magnitude lose their
+ * second / third piece to bf16's exponent range (absolute error <= 2^-8 |a| |b| for those terms, i.e. <= 4e-36 |b|):
+ * invisible unless the other operand is astronomically large.  Use mode 0 for data outside these ranges.
  * mode 0: every product on the fp32 matrix instruction (v_mfma_f32_32x32x2_f32, an exact fp32 fma chain).
  * mode 1: operands rounded to bf16 on their way into
  * LDS, f32 accumulate (v_mfma_f32_32x32x16_bf16) for every product with M, N, K >= 128 (conv views included); tensors in HBM

@@ -254,10 +254,10 @@ size_t nr_conv1d_k3_bwd_ws_bytes(int64_t M, int64_t T, int64_t E, int64_t D) {
 struct SideStream {
     hipStream_t s = nullptr; hipEvent_t fork[4] = {}, join = nullptr; bool ok = false;
     std::mutex mu;                          // record + wait of one event as a pair: host threads may share the GPU
-    void edge(hipEvent_t ev, hipStream_t from, hipStream_t to) {
+    hipError_t edge(hipEvent_t ev, hipStream_t from, hipStream_t to) {
         std::lock_guard<std::mutex> lk(mu);
-        (void)hipEventRecord(ev, from);
-        (void)hipStreamWaitEvent(to, ev, 0);
+        const hipError_t e = hipEventRecord(ev, from);
+        return e != hipSuccess ? e : hipStreamWaitEvent(to, ev, 0);
     }
 };
 static SideStream* side_stream() {
@@ -275,9 +275,32 @@ static SideStream* side_stream() {
     }
     return ss.ok ? &ss : nullptr;
 }
-struct SideJoin {                               // the main stream waits for the side stream on every way out
-    SideStream* ss; hipStream_t main;
-    ~SideJoin() { if (ss) ss->edge(ss->join, ss->s, main); }
+// One layer backward's use of the second stream.  fork(i): the side stream waits for everything queued on the main
+// stream so far; if that edge cannot be made, the products that would have followed it go to the MAIN stream instead
+// (stream() hands out the main stream from then on: slower, never unordered).  finish() — also run by the destructor on
+// early returns — makes the main stream wait for the side stream; if THAT edge fails the side stream is drained on the
+// host and the call reports NR_ERR_LAUNCH, so no caller ever reads a gradient that is still being written.
+struct SideUse {
+    SideStream* ss; hipStream_t main; bool joined = false, used = false;
+    SideUse(SideStream* ss_, hipStream_t main_) : ss(ss_), main(main_) {}
+    hipStream_t stream() const { return ss ? ss->s : main; }
+    void fork(int i) {
+        if (!ss) return;
+        if (ss->edge(ss->fork[i], main, ss->s) == hipSuccess) { used = true; return; }
+        (void)hipGetLastError();
+        if (used) (void)finish();              // earlier products are on the side stream: order the main stream behind them
+        ss = nullptr;                           // from here on everything runs on the caller's stream
+    }
+    int finish() {
+        if (joined || !ss || !used) { joined = true; return NR_OK; }
+        joined = true;
+        if (ss->edge(ss->join, ss->s, main) == hipSuccess) return NR_OK;
+        (void)hipGetLastError();
+        (void)hipStreamSynchronize(ss->s);
+        set_error("side stream: joining the weight-gradient stream failed (drained it on the host instead)");
+        return NR_ERR_LAUNCH;
+    }
+    ~SideUse() { (void)finish(); }
 };
 static const int64_t SIDE_MIN_ROWS = getenv("NR_SIDE_MIN_ROWS") ? atoll(getenv("NR_SIDE_MIN_ROWS")) : 1024;
 
@@ -289,9 +312,9 @@ int nr_conv1d_k3_bwd_f32(const float* dy, const float* x, const float* wpack, in
     const int64_t R = M * T;
     // the weight gradient (and its unpacking) on the second stream, beside the input gradient
     SideStream* ss = (dx && R >= SIDE_MIN_ROWS) ? side_stream() : nullptr;
-    SideJoin join{ss, s};
-    const hipStream_t sw = ss ? ss->s : s;
-    if (ss) ss->edge(ss->fork[0], s, sw);
+    SideUse su(ss, s);
+    su.fork(0);
+    const hipStream_t sw = su.stream();
     if (dx) {
         GemmParams p;
         p.A = dy - D; p.lda = D; p.B = wpack + D * 3 * E; p.ldb = 3 * D; p.C = dx; p.ldc = E;
@@ -303,7 +326,8 @@ int nr_conv1d_k3_bwd_f32(const float* dy, const float* x, const float* wpack, in
     float* gwf = bump(cur, (size_t)D * 3 * E);
     const size_t rest = ws_bytes - (size_t)(cur - (char*)ws);
     if (int rc = linear_bwd_weight(dy, D, x - E, E, R, D, 3 * E, gwf, db, cur, rest, (int)T, (int)E, sw)) return rc;
-    return conv_unpack_grad(gwf, dw, (int)D, (int)E, sw);
+    if (int rc = conv_unpack_grad(gwf, dw, (int)D, (int)E, sw)) return rc;
+    return su.finish();
 }
 
 int nr_add_layernorm_fwd_f32(const float* h, const float* x, int64_t x_period, const float* gamma, const float* beta, int64_t R, int64_t D, float eps, float p_drop, uint64_t seed, uint32_t site, float* y, float* s_out, float* mean, float* rstd, void* stream) {
@@ -703,9 +727,9 @@ static int tfm_layer_bwd(const float* dy, const float* x, const int64_t* mask, i
     const float* wqkv = contiguous3(w->wq, w->wk, w->wv, DD) ? w->wq : sv->wqkv;
     NR_CHECK_ARG(wqkv, "tfm_layer_bwd: q/k/v weights are not contiguous and no packed copy saved");
     SideStream* ss = R >= SIDE_MIN_ROWS ? side_stream() : nullptr;
-    SideJoin join{ss, s};
-    const hipStream_t sw = ss ? ss->s : s;                   // stream of the weight-gradient products
-    auto fork = [&](int i) { if (ss) ss->edge(ss->fork[i], s, sw); };
+    SideUse su(ss, s);
+    hipStream_t sw = su.stream();                            // stream of the weight-gradient products
+    auto fork = [&](int i) { su.fork(i); sw = su.stream(); };
 
     // LN2 <- dy
     if (int rc = layernorm_bwd_rows(dy, sv->s2, mean2, rstd2, w->ln2_g, R, (int)D, DCP(DC(p_drop, seed, site_base + 2), nullptr, row_map), ds2,
@@ -744,7 +768,8 @@ static int tfm_layer_bwd(const float* dy, const float* x, const int64_t* mask, i
             if (int rc = copy_d2d(dbs[i], dbqkv + i * D, D * sizeof(float), sw)) return rc;
         }
     }
-    return linear_bwd_input(dqkv, 3 * D, wqkv, R, 3 * D, D, EPI_ADD_AUX, ds1, nullptr, dx, s);
+    if (int rc = linear_bwd_input(dqkv, 3 * D, wqkv, R, 3 * D, D, EPI_ADD_AUX, ds1, nullptr, dx, s)) return rc;
+    return su.finish();
 }
 
 int nr_tfm_layer_bwd_f32(const float* dy, const float* x, const int64_t* mask, int64_t N, int64_t Sq, int64_t D, int64_t H, const nr_tfm_weights* w, float p_drop, uint64_t seed, uint32_t site_base, int mask_mode, const nr_tfm_saved* sv, nr_tfm_grads* g, float* dx, void* ws, size_t ws_bytes, void* stream) {
@@ -872,9 +897,9 @@ int nr_tfm_layer_bwd_bf16(const float* dy, const int64_t* mask, const int32_t* o
     // column sums) runs on the second stream, in order, so dhT / actT / dzT / cpart / slabs are reused there without
     // hazards; the main stream keeps LayerNorm, the weight transposes, the dX products and the attention backward.
     SideStream* ss = R >= SIDE_MIN_ROWS ? side_stream() : nullptr;
-    SideJoin join{ss, s};
-    const hipStream_t sw = ss ? ss->s : s;
-    auto fork = [&](int i) { if (ss) ss->edge(ss->fork[i], s, sw); };
+    SideUse su(ss, s);
+    hipStream_t sw = su.stream();
+    auto fork = [&](int i) { su.fork(i); sw = su.stream(); };
 
     // LN2 <- dy
     if (int rc = layernorm_bwd(dy, sv->s2, mean2, rstd2, w->ln2_g, R, (int)D, DCP(DC(p_drop, seed, site_base + 2), nullptr, row_map), ds2, p_drop > 0.f ? dh2 : nullptr, g->dln2_g, g->dln2_b, lnws, s, dh_h)) return rc;
@@ -916,7 +941,8 @@ int nr_tfm_layer_bwd_bf16(const float* dy, const int64_t* mask, const int32_t* o
     if (int rc = gemm_dw(dzT, actT, 3 * D, D, Rp, g->dwq, slabs, slab_bytes, sw)) return rc;
     if (int rc = colsum_h(dqkv_h, 3 * D, R, (int)(3 * D), g->dbq, cpart, sw)) return rc;
     if (int rc = transpose_bf16(w->wq, 0, D, 3 * D, D, wT, 3 * D, s)) return rc;                       // [3D,D] -> [D,3D]
-    return gemm_nt(dqkv_h, 3 * D, wT, 3 * D, R, D, 3 * D, nullptr, EPI_ADD_AUX, dx, nullptr, ds1, nullptr, nullptr, s);
+    if (int rc = gemm_nt(dqkv_h, 3 * D, wT, 3 * D, R, D, 3 * D, nullptr, EPI_ADD_AUX, dx, nullptr, ds1, nullptr, nullptr, s)) return rc;
+    return su.finish();
 }
 
 // ------------------------------------------------------------------------------------ GRU user encoder

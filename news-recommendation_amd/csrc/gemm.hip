@@ -843,7 +843,7 @@ static int launch_bf16(const GemmParams& p, hipStream_t s) {
 // which together carry all 24 significand bits, and a*b is accumulated in fp32 from the six piece products of weight
 // >= 2^-16:  a0*b2 + a2*b0 + a1*b1 + a0*b1 + a1*b0 + a0*b0  (smallest first).  Each bf16 x bf16 product is exact in
 // fp32; the three dropped products (a1*b2, a2*b1, a2*b2) are below 2^-23 |a*b|, the size of fp32's own rounding of
-// the product.  v_mfma_f32_32x32x16_bf16 retires 8x the multiply-adds per cycle of v_mfma_f32_32x32x2_f32, so six
+// the product.  v_mfma_f32_32x32x16_bf16 retires 16x the multiply-adds per cycle of v_mfma_f32_32x32x2_f32, so six
 // of them per k-step still run 2.7x faster than the fp32 instruction while the result keeps fp32 accuracy (the parity
 // tests hold this path to the same 1e-5 as the fp32 MFMA kernel).  Same operands in HBM (fp32), layouts, conv views,
 // epilogues, split-K and fused column sums as gemm_f32_kernel; loaders / LDS layout of gemm_bf16_kernel above, with

@@ -20,16 +20,15 @@ static __device__ int g_index_flag;
 int* index_flag_ptr() {
     static std::mutex mu;
     static int* per_dev[64];
-    static bool tried[64];
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
     std::lock_guard<std::mutex> lk(mu);
-    if (!tried[dev]) {
-        tried[dev] = true;
+    if (!per_dev[dev]) {
+        // looked up again on the next call if it fails now (a first call under stream capture, say): a failure must not
+        // switch the out-of-range detection off for the rest of the process.  No memset: a __device__ int starts at 0.
         int* ptr = nullptr;
-        if (hipGetSymbolAddress(reinterpret_cast<void**>(&ptr), HIP_SYMBOL(g_index_flag)) == hipSuccess && ptr &&
-            hipMemset(ptr, 0, sizeof(int)) == hipSuccess)
-            per_dev[dev] = ptr;
+        if (hipGetSymbolAddress(reinterpret_cast<void**>(&ptr), HIP_SYMBOL(g_index_flag)) == hipSuccess && ptr) per_dev[dev] = ptr;
+        else (void)hipGetLastError();
     }
     return per_dev[dev];
 }
@@ -37,7 +36,10 @@ int index_status(int* host_out, hipStream_t s) {
     NR_CHECK_ARG(host_out, "nr_index_status: null output");
     *host_out = 0;
     int* flag = index_flag_ptr();
-    if (!flag) return NR_OK;
+    if (!flag) {        // the gathers ran without a flag: their clamped indices went unreported, say so
+        set_error("nr_index_status: the per-GPU index flag is unavailable (hipGetSymbolAddress failed): out-of-range indices cannot be reported");
+        return NR_ERR_LAUNCH;
+    }
     if (hipMemcpyAsync(host_out, flag, sizeof(int), hipMemcpyDeviceToHost, s) != hipSuccess || hipMemsetAsync(flag, 0, sizeof(int), s) != hipSuccess ||
         hipStreamSynchronize(s) != hipSuccess) {
         set_error("nr_index_status: reading the flag failed");

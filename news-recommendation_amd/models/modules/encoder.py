@@ -265,16 +265,16 @@ class AllBertNewsEncoder(BaseNewsEncoder):
 
 
 class RnnUserEncoder(BaseUserEncoder):
+    """final GRU state over the clicked-news vectors (the default -ue of main.twotower).  ``self.rnn`` is an
+    nn.GRU used as a parameter container only (reference key names rnn.weight_ih_l0 …); the recurrence runs
+    in the HIP library (input half as one MFMA GEMM, 2 small launches per step, no lens.cpu() sync)."""
+
     @staticmethod
     def history_keep(his_mask):
         """[B,L] 0/1: the history slots that can reach the result.  The packed GRU reads the first len = sum(his_mask)
         slots and nothing else (reference encoder.py:226-232)."""
         L = his_mask.shape[1]
         return (torch.arange(L, device=his_mask.device)[None, :] < his_mask.sum(1, keepdim=True)).long()
-
-    """final GRU state over the clicked-news vectors (the default -ue of main.twotower).  ``self.rnn`` is an
-    nn.GRU used as a parameter container only (reference key names rnn.weight_ih_l0 …); the recurrence runs
-    in the HIP library (input half as one MFMA GEMM, 2 small launches per step, no lens.cpu() sync)."""
 
     def __init__(self, manager):
         super().__init__()

@@ -114,6 +114,16 @@ def gather_rows_i64(table, idx):
     return words.view(torch.int64)
 
 
+# callbacks run when a backward reaches the token table's scatter-add: every other parameter gradient of the step is
+# final by then (utils/dp.py starts the dense parameters' all-reduce here so that it overlaps the scatter-add)
+table_backward_hooks = []
+
+
+def _table_backward():
+    for fn in tuple(table_backward_hooks):
+        fn()
+
+
 class _Embedding(torch.autograd.Function):
     @staticmethod
     def forward(ctx, table, ids, padding_idx):
@@ -128,6 +138,8 @@ class _Embedding(torch.autograd.Function):
         (ids,) = ctx.saved_tensors
         g = _f32(g, "grad")
         V, E = ctx.shape
+        if V * E >= 1 << 20:                   # a token table (not a small positional one)
+            _table_backward()
         gt = torch.zeros(V, E, dtype=torch.float32, device=g.device)
         check(lib().nr_scatter_add_rows_f32(_p(g), _p(ids), ids.numel(), E, V, ctx.padding_idx, _p(gt), _stream()),
               "nr_scatter_add_rows_f32")
@@ -776,19 +788,21 @@ def bert_embeddings(word, pos, typ, gamma, beta, ids, eps=LN_EPS, p_drop=0.0, se
 
 class _FirstRows(torch.autograd.Function):
     """x [rows, D] packed -> the first row of every sequence [N, D] ([CLS] states).  Sequences without rows (titles the
-    caller never uses) return whatever row their offset points at: finite, and by the caller's guarantee unused."""
+    caller marked as never used) come back as zero vectors and send no gradient anywhere, as the pooling path does:
+    a user encoder with a looser history_keep can then neither read another title's vector nor leak a gradient into it."""
 
     @staticmethod
     def forward(ctx, x, plan):
         idx = plan.offs[:-1].long().clamp_(max=max(plan.rows - 1, 0))
-        ctx.save_for_backward(idx)
+        empty = (plan.offs[1:] == plan.offs[:-1]).unsqueeze(1)
+        ctx.save_for_backward(idx, empty)
         ctx.shape = x.shape
-        return gather_rows(x, idx)
+        return gather_rows(x, idx).masked_fill_(empty, 0.0)
 
     @staticmethod
     def backward(ctx, g):
-        (idx,) = ctx.saved_tensors
-        g = _f32(g, "grad")
+        idx, empty = ctx.saved_tensors
+        g = _f32(g, "grad").masked_fill(empty, 0.0)
         R, D = ctx.shape
         dx = torch.zeros(R, D, dtype=torch.float32, device=g.device)
         check(lib().nr_scatter_add_rows_f32(_p(g), _p(idx), idx.numel(), D, R, -1, _p(dx), _stream()), "nr_scatter_add_rows_f32")

@@ -1,11 +1,12 @@
 """Data-parallel gradient averaging for the two-tower model (one process per GPU, RCCL over xGMI).
 
 The reference wraps the model in DistributedDataParallel (main/twotower.py:40-41).  Here the step is: drop the
-gradients -> backward -> ONE multi-tensor copy of the fresh gradients into a flat fp32 buffer -> one all-reduce
-(average) over the buffer -> Adam on views of the buffer.  No autograd hooks and no communication thread beside the
-backward.  The design reason: of the 46 MB reduced per step at 300-d, 36.6 MB are the dense token-table gradient,
-which is the LAST thing the backward produces, so DDP's bucket overlap had ~10 MB to hide, and one large collective
-uses the xGMI links better than several 25 MB buckets.
+gradients -> backward -> multi-tensor copies of the fresh gradients into a flat fp32 buffer laid out
+[dense parameters | token table] -> TWO all-reduces (the 9.4 MB dense part starts when the backward reaches the token
+table's scatter-add and overlaps it; the 36.6 MB table part follows) -> one 1/N scale -> Adam on views of the buffer.
+No per-parameter autograd hooks and no communication thread beside the backward.  The design reason: the token-table
+gradient is the LAST thing the backward produces, so DDP's 25 MB bucket overlap had ~10 MB to hide; two large
+collectives use the xGMI links better than several buckets and keep the step rehearsable on one GPU.
 
 What is known about DistributedDataParallel with this library (round 1 records, gpurun_out/ddp_steps_*): wrapped in
 torch's DDP over GLOO with TWO PROCESSES ON ONE GPU, both ranks stalled in the first backward (main thread in
@@ -66,25 +67,78 @@ def all_gather_list(t, world):
     return bufs
 
 
-class FlatGradSync(torch.nn.Module):
-    """wraps the model like DDP does (`.module`, same forward); call zero_grad() before and sync() after backward."""
+def all_reduce_async(t):
+    """start a SUM all-reduce of `t`; returns a handle whose wait() orders the current stream behind it.  Under gloo on
+    device tensors (rehearsal) it runs synchronously through the host and returns None."""
+    if _staged(t):
+        all_reduce_(t)
+        return None
+    return dist.all_reduce(t, async_op=True)
 
-    def __init__(self, module, world_size=None):
+
+# token tables: their dense [V, E] gradient is the LAST thing a backward produces (the embedding is the first op of the
+# forward) and by far the largest (36.6 of 46 MB at 300-d)
+LATE_SUFFIXES = ("embedding.weight", "word_embeddings.weight")
+
+
+class FlatGradSync(torch.nn.Module):
+    """wraps the model like DDP does (`.module`, same forward); call zero_grad() before and sync() after backward.
+
+    The flat buffer is laid out [dense parameters | token tables] and reduced as TWO collectives: the dense part
+    (9.4 MB at 300-d) is packed and its all-reduce started as soon as the backward reaches the token table's scatter-add
+    (ops.table_backward_hooks: every other gradient is final by then, the autograd engine runs parameter accumulation
+    ahead of other nodes), so it travels while the scatter-add runs; the table part follows in sync().  Without the hook
+    (CPU tests, torch modules) sync() issues both, one after the other: same result."""
+
+    def __init__(self, module, world_size=None, late_suffixes=LATE_SUFFIXES):
         super().__init__()
         self.module = module
         self.world = world_size if world_size is not None else (dist.get_world_size() if dist.is_initialized() else 1)
-        self.params = [p for p in module.parameters() if p.requires_grad]
+        named = [(n, p) for n, p in module.named_parameters() if p.requires_grad]
+        late = [(n, p) for n, p in named if n.endswith(tuple(late_suffixes))]
+        early = [(n, p) for n, p in named if not n.endswith(tuple(late_suffixes))]
+        self.params = [p for _, p in early + late]
+        self.n_early_params = len(early)
         n = sum(p.numel() for p in self.params)
         ref = self.params[0]
         self.flat = torch.zeros(n, dtype=ref.dtype, device=ref.device)
         self.views, off = [], 0
-        for p in self.params:
+        for i, p in enumerate(self.params):
+            if i == self.n_early_params:
+                self.n_early = off
             self.views.append(self.flat[off:off + p.numel()].view_as(p))
             off += p.numel()
+        if not late:
+            self.n_early = off
+        self.flat_early, self.flat_late = self.flat[:self.n_early], self.flat[self.n_early:]
+        self._early_done, self._works, self._dirty = False, [], False
         if self.world > 1:                       # replicas start from rank 0's weights (and buffers), like DDP
             with torch.no_grad():
                 for t in list(module.parameters()) + list(module.buffers()):
                     broadcast_(t.data, 0)
+        try:                                     # the HIP path announces "only the token table's gradient is left"
+            from newsrec_hip import ops
+            import weakref
+            me = weakref.ref(self)
+
+            def hook():
+                obj = me()
+                if obj is not None and obj.flat.is_cuda:
+                    if obj._early_done:         # a second backward since zero_grad(): its gradients would miss the reduce
+                        obj._dirty = True
+                    obj.sync_early()
+            self._hook = hook
+            ops.table_backward_hooks.append(hook)
+        except ImportError:
+            self._hook = None
+
+    def __del__(self):
+        try:
+            from newsrec_hip import ops
+            if self._hook in ops.table_backward_hooks:
+                ops.table_backward_hooks.remove(self._hook)
+        except Exception:       # noqa: BLE001 — interpreter shutdown
+            pass
 
     def forward(self, *args, **kwargs):
         return self.module(*args, **kwargs)
@@ -95,12 +149,15 @@ class FlatGradSync(torch.nn.Module):
         DDP / optimizer call-site compatibility; the gradients are always dropped."""
         for p in self.params:
             p.grad = None
+        if self._works:                          # a step abandoned between backward and sync(): let its collective finish
+            for w in self._works:
+                if w is not None:
+                    w.wait()
+        self._early_done, self._works, self._dirty = False, [], False
 
-    @torch.no_grad()
-    def sync(self):
-        """pack the gradients into the flat buffer, average it over the ranks in place, and leave every .grad a view of it"""
+    def _pack(self, lo, hi):
         src, dst = [], []
-        for p, v in zip(self.params, self.views):
+        for p, v in zip(self.params[lo:hi], self.views[lo:hi]):
             if p.grad is None:
                 v.zero_()                            # a parameter the loss did not reach contributes zeros to the average
             elif p.grad is not v:
@@ -108,9 +165,34 @@ class FlatGradSync(torch.nn.Module):
                 dst.append(v)
         if src:
             torch._foreach_copy_(dst, src)
-        for p, v in zip(self.params, self.views):
+        for p, v in zip(self.params[lo:hi], self.views[lo:hi]):
             p.grad = v
+
+    @torch.no_grad()
+    def sync_early(self):
+        """pack the dense parameters' gradients and start their all-reduce (once per step; later calls do nothing)"""
+        if self._early_done:
+            return
+        self._early_done = True
+        self._pack(0, self.n_early_params)
+        if self.world > 1 and self.n_early:
+            self._works.append(all_reduce_async(self.flat_early))
+
+    @torch.no_grad()
+    def sync(self):
+        """pack the gradients into the flat buffer, average it over the ranks in place, and leave every .grad a view of it"""
+        if self._dirty:
+            raise RuntimeError("FlatGradSync: two backward passes between zero_grad() and sync() — the dense parameters' "
+                               "all-reduce started during the first one; call zero_grad() before every backward")
+        self.sync_early()
+        self._pack(self.n_early_params, len(self.params))
         if self.world <= 1:
             return
-        all_reduce_(self.flat)                       # SUM, then one in-place scale (exact for 2, 4, 8 ranks): no reliance on
-        self.flat.div_(self.world)                   # the backend offering an AVG reduction
+        if self.flat_late.numel():
+            self._works.append(all_reduce_async(self.flat_late))
+        for w in self._works:
+            if w is not None:
+                w.wait()
+        self._works = []
+        self.flat.div_(self.world)                   # SUM, then one in-place scale (exact for 2, 4, 8 ranks): no reliance on
+                                                     # the backend offering an AVG reduction

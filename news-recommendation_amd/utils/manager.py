@@ -153,6 +153,8 @@ class Manager():
         self.dataloaders = _LOADERS[self.mode]
         self.rank = 0
         self.distributed = self.world_size > 1
+        if self.distributed:                       # inherited by the mp.spawn children before their first GPU call (see setup)
+            os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         self.exclude_hparams = set([
             "news_nums", "vocab_size_map", "metrics", "plm_dim", "plm_dir", "data_root", "cache_root", "distributed",
             "exclude_hparams", "rank", "epochs", "mode", "debug", "special_token_ids", "validate_step", "hold_step",
@@ -161,17 +163,29 @@ class Manager():
 
     # ------------------------------------------------------------------ runtime
     def setup(self, rank):
-        """one process per GPU; RCCL process group when world_size > 1"""
+        """one process per GPU; RCCL process group when world_size > 1 (reference manager.py:189-217).
+        The environment RCCL needs on this platform is set here, so `python -m main.twotower -ws 8` has what
+        `bench.py --gpus 8` has: HSA_ENABLE_IPC_MODE_LEGACY=0 (the host driver only offers dmabuf IPC; without it RCCL's
+        buffer exchange fails with hipIpcGetMemHandle: invalid argument) — set before this process makes its first GPU
+        call (Manager.__init__ sets it too, so that mp.spawn children inherit it) — and the process group is bound to its
+        device (device_id=), so the communicator is created eagerly on the right GPU and barriers need no device guess.
+        NR_REHEARSE_ONE_GPU=1 (tests only, never set by the product): every rank on device 0 over gloo, the multi-rank
+        logic without N GPUs."""
         os.environ["TOKENIZERS_PARALLELISM"] = "True"
         if self.world_size > 1:
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             os.environ.setdefault("MASTER_PORT", str(12355 + self.base_rank))
-            backend = "gloo" if self.device == "cpu" else "nccl"
+            os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+            rehearse = os.environ.get("NR_REHEARSE_ONE_GPU") == "1"
+            backend = "gloo" if (self.device == "cpu" or rehearse) else "nccl"
             self.rank = rank
+            kw = {}
             if self.device != "cpu":
-                self.device = rank + self.base_rank
+                self.device = self.base_rank if rehearse else rank + self.base_rank
                 torch.cuda.set_device(self.device)
-            dist.init_process_group(backend, rank=rank, world_size=self.world_size, timeout=timedelta(0, 1000000))
+                if backend == "nccl":
+                    kw["device_id"] = torch.device("cuda", self.device)
+            dist.init_process_group(backend, rank=rank, world_size=self.world_size, timeout=timedelta(0, 1000000), **kw)
         else:
             self.rank = 0
             if self.device != "cpu":

@@ -256,6 +256,12 @@ class HipAdam(torch.optim.Optimizer):
         super().load_state_dict(state_dict)
         self._tables = {}                     # the moments are new tensors now
 
+    def __getstate__(self):
+        """the cached ctypes pointer tables never leave the process (copy.deepcopy / pickle / torch.save of the optimizer)"""
+        st = super().__getstate__()
+        st.pop("_tables", None)
+        return st
+
     @torch.no_grad()
     def step(self, closure=None):
         from newsrec_hip import ops
@@ -270,7 +276,13 @@ class HipAdam(torch.optim.Optimizer):
                 continue
             # everything about the step except the gradient pointers is the same from step to step (the same tensors get
             # gradients, parameters and moments do not move): the pointer tables of the fused launch are built once
-            key = tuple((id(p), p.data_ptr()) for p in ps)      # a parameter moved by .to() / .data = ... rebuilds them
+            # (a parameter moved by .to() / .data = ..., or a moment tensor replaced in self.state by any route, rebuilds them)
+            state = self.state
+            key = []
+            for p in ps:
+                st = state.get(p)
+                key.append((id(p), p.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr()) if st else (id(p), p.data_ptr(), 0, 0))
+            key = tuple(key)
             cache = getattr(self, "_tables", {}).get(gi)
             if cache is None or cache["key"] != key:
                 for p in ps:
@@ -282,6 +294,7 @@ class HipAdam(torch.optim.Optimizer):
                     if not p.is_contiguous():     # the kernel walks flat memory
                         raise RuntimeError("HipAdam: parameters must be contiguous")
                 states = [self.state[p] for p in ps]
+                key = tuple((id(p), p.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr()) for p, st in zip(ps, states))
                 cache = {"key": key, "states": states,
                          "static": ops.adam_tables(ps, [st["exp_avg"] for st in states], [st["exp_avg_sq"] for st in states])}
                 if not hasattr(self, "_tables"):

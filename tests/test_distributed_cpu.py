@@ -109,12 +109,21 @@ def _grad_sync_worker(rank, world, port, q):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from utils.dp import FlatGradSync
     torch.manual_seed(100 + rank)                       # replicas start DIFFERENT: the wrapper must broadcast rank 0's weights
-    net = torch.nn.Sequential(torch.nn.Embedding(50, 8), torch.nn.Linear(8, 8), torch.nn.Tanh(), torch.nn.Linear(8, 1))
+    class Net(torch.nn.Module):              # `embedding.weight` = a token table: the LATE piece of the flat buffer (utils/dp.py)
+        def __init__(self):
+            super().__init__()
+            self.embedding = torch.nn.Embedding(50, 8)
+            self.body = torch.nn.Sequential(torch.nn.Linear(8, 8), torch.nn.Tanh(), torch.nn.Linear(8, 1))
+
+        def forward(self, ids):
+            return self.body(self.embedding(ids))
+    net = Net()
     dp = FlatGradSync(net, world)
+    assert 0 < dp.n_early < dp.flat.numel() and dp.flat_late.numel() == 50 * 8 and dp.params[-1] is net.embedding.weight
     opt = torch.optim.Adam(net.parameters(), lr=1e-2)
     g = torch.Generator().manual_seed(7)
     ids = torch.randint(0, 50, (8, 5), generator=g)     # the full batch; rank r takes rows r::world
-    full = torch.nn.Sequential(torch.nn.Embedding(50, 8), torch.nn.Linear(8, 8), torch.nn.Tanh(), torch.nn.Linear(8, 1))
+    full = Net()
     full.load_state_dict(net.state_dict())
     full_opt = torch.optim.Adam(full.parameters(), lr=1e-2)
     for _ in range(3):

@@ -550,7 +550,12 @@ def test_full_size_step_properties():
     assert torch.isfinite(l0) and l0.item() > 0
     assert torch.equal(l0, l1)
     for n in g0:
-        if "embedding" in n:                   # float atomics: order-dependent in the last bits
+        if "embedding" in n:
+            # float atomics: the order in which a token's rows are added differs from run to run.  [CLS] / [SEP] rows are
+            # sums of ~1 088 addends, so two orders differ by up to ~sqrt(1088) * 2^-24 ~ 2e-6 of the row's scale; the
+            # first bound tried here (1e-6) failed at 1.04e-6 for exactly that reason (round 2 records) and 5e-6 is what
+            # the arithmetic allows, not a fitted number.  The sum itself is pinned against float64 at this size by
+            # test_gpu_kernels.py::test_scatter_add_full_size_vs_float64 (every row within 2e-6 of its own scale).
             assert relerr(g1[n], g0[n]) < 5e-6, n
         else:
             assert torch.equal(g0[n], g1[n]), n

@@ -1,5 +1,5 @@
 """embedding scatter-add with and without two hot ids ([CLS] / [SEP] of every title): the hot rows serialise their atomics
-(GPU box only: python tools/scatter_test.py)"""
+(GPU box only: python tools/scatter_probe.py)"""
 import os, sys
 sys.path.insert(0, "/root/repo/news-recommendation_amd")
 import torch
