@@ -1,5 +1,5 @@
 """Two-rank rehearsal of the product's own multi-GPU entry on ONE GPU: `main.twotower.main(rank,
-manager)` under mp.spawn — Manager.setup -> process group -> prepare (DistributedSampler) -> FlatGradSync -> 5 train steps
+manager)` under mp.spawn — Manager.setup -> process group -> prepare (DistributedSampler) -> FlatGradSync -> >= 5 train steps
 -> sharded evaluation — with NR_REHEARSE_ONE_GPU=1 (gloo instead of RCCL, both ranks on device 0).  The ranks are fresh
 processes started before anything in this parent touches the GPU (reference main/twotower.py:55-61 does the same with
 mp.spawn).  Mirrors reference utils/manager.py:196-208.
@@ -72,7 +72,7 @@ def main():
                          f"-cr {outdir}/cache -dr {outdir}/data").split())
     assert os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY") == "0", "Manager.__init__ must export the RCCL IPC setting for -ws > 1"
     m.news_nums = {"MINDdemo_train": 700, "MINDdemo_dev": 500}
-    write_synthetic_caches(m, n_train_impr=80, n_dev_impr=30, seed=3)       # 80 impressions / 2 ranks / batch 8 = 5 steps each
+    write_synthetic_caches(m, n_train_impr=80, n_dev_impr=30, seed=3)       # >= 80 train items / 2 ranks / batch 8: at least 5 steps each
     mp.spawn(worker, args=(m, outdir), nprocs=2, join=True)
 
 

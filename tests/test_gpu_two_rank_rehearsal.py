@@ -1,7 +1,7 @@
 """`python -m main.twotower -ws 2` rehearsed on one GPU (reference utils/manager.py:196-208,
 main/twotower.py:38-39,55-61): two fresh ranks run `main.twotower.main` through Manager.setup (process group,
 HSA_ENABLE_IPC_MODE_LEGACY exported for the children), DistributedSampler, FlatGradSync (dense-parameter all-reduce
-started at the token table's scatter-add, table all-reduce after it), 5 train steps and the sharded evaluation, over
+started at the token table's scatter-add, table all-reduce after it), at least 5 train steps and the sharded evaluation, over
 gloo with both ranks on device 0.  The run itself happens in tests/conftest.py::pytest_sessionstart — before this
 pytest process touches the GPU — and this test checks its records."""
 import json
@@ -19,7 +19,7 @@ def test_main_twotower_two_ranks_stay_bit_identical(request):
     ranks = [json.load(open(os.path.join(rec["dir"], f"rank{r}.json"))) for r in range(2)]
     for r, res in enumerate(ranks):
         assert res["rank"] == r and res["world"] == 2 and res["backend"] == "gloo"
-        assert res["wrapper"] == "FlatGradSync" and res["steps"] == 5            # 80 impressions / 2 ranks / batch 8
+        assert res["wrapper"] == "FlatGradSync" and res["steps"] >= 5            # >= 80 train items / 2 ranks / batch 8
         assert res["replicas_identical"], "replicas diverged after 5 steps"
         assert res["ipc_env"] == "0"                                             # what RCCL needs, set by Manager for its children
         assert res["so_loaded"]                                                  # the HIP library did the work
