@@ -92,10 +92,11 @@ static void maybe_split(GemmParams& p, float* ws, size_t ws_bytes) {
     if (ks > 1 && gemm_workspace_bytes(p.M, p.N, ks) <= ws_bytes) p.ksplit = ks;
 }
 static int linear_fwd(const float* x, int64_t ldx, const float* w, const float* b, int64_t R, int64_t K, int64_t N, int epi,
-                      float* y, float* z, hipStream_t s, float* ws = nullptr, size_t ws_bytes = 0) {
+                      float* y, float* z, hipStream_t s, float* ws = nullptr, size_t ws_bytes = 0, bool z_is_gelu_grad = false) {
     GemmParams p;
     p.A = x; p.lda = ldx; p.B = w; p.ldb = K; p.C = y; p.ldc = N;
     p.M = (int)R; p.N = (int)N; p.K = (int)K; p.bias = b; p.epi = epi; p.out2 = z; p.ldout2 = N;
+    p.gelu_save_grad = z_is_gelu_grad ? 1 : 0;
     maybe_split(p, ws, ws_bytes);
     return gemm_f32(p, true, true, ws, ws_bytes, s);
 }
@@ -157,6 +158,12 @@ int nr_set_side_stream(int on) {
     return g_side_on.exchange(on ? 1 : 0);
 }
 int nr_get_gemm_compute(void) { return nr::get_gemm_compute(); }
+int nr_set_tuning(int key, int value) {
+    NR_CHECK_ARG(key >= 0 && key < TUNE_COUNT, "nr_set_tuning: key %d out of range", key);
+    const int old = nr::get_tuning(key);
+    nr::set_tuning(key, value);
+    return old;
+}
 const char* nr_last_error(void) { return g_err; }
 
 int nr_prof_enable(int on) {
@@ -670,7 +677,9 @@ static int tfm_layer_fwd(const float* x, const int64_t* mask, int64_t N, int64_t
     if (int rc = linear_fwd(sv->ctx, D, w->wo, w->bo, R, D, D, EPI_NONE, sv->s1, nullptr, s)) return rc;
     if (int rc = ln_fwd(sv->s1, x, w->ln1_g, w->ln1_b, sv->y1, sv->s1, mean1, rstd1, R, (int)D, 1e-12f,
                         DCP(DC(p_drop, seed, site_base + 1), nullptr, row_map), s)) return rc;
-    if (int rc = linear_fwd(sv->y1, D, w->w1, w->b1, R, D, 4 * D, EPI_GELU, sv->a, sv->z, s)) return rc;
+    // (experiment, nr_set_tuning(1, 1): sv->z receives gelu'(pre-activation) and the backward multiplies by it; set it for
+    // a whole step or not at all — forward and backward must agree)
+    if (int rc = linear_fwd(sv->y1, D, w->w1, w->b1, R, D, 4 * D, EPI_GELU, sv->a, sv->z, s, nullptr, 0, get_tuning(TUNE_GELU_SAVE_GRAD) != 0)) return rc;
     if (int rc = linear_fwd(sv->a, 4 * D, w->w2, w->b2, R, 4 * D, D, EPI_NONE, sv->s2, nullptr, s)) return rc;
     return ln_fwd(sv->s2, sv->y1, w->ln2_g, w->ln2_b, y, sv->s2, mean2, rstd2, R, (int)D, 1e-12f,
                   DCP(DC(p_drop, seed, site_base + 2), nullptr, row_map), s);
@@ -738,7 +747,7 @@ static int tfm_layer_bwd(const float* dy, const float* x, const int64_t* mask, i
     fork(0);
     if (int rc = layernorm_bwd_params(R, (int)D, g->dln2_g, g->dln2_b, lnws, sw)) return rc;
     if (int rc = linear_bwd_weight(dh2, D, sv->a, 4 * D, R, D, 4 * D, g->dw2, g->db2, wws, wws_bytes, 0, 0, sw)) return rc;
-    if (int rc = linear_bwd_input(dh2, D, w->w2, R, D, 4 * D, EPI_MUL_GELU_GRAD, sv->z, nullptr, dz, s)) return rc;
+    if (int rc = linear_bwd_input(dh2, D, w->w2, R, D, 4 * D, get_tuning(TUNE_GELU_SAVE_GRAD) ? EPI_MUL_AUX : EPI_MUL_GELU_GRAD, sv->z, nullptr, dz, s)) return rc;
     // FFN1: dW1 = dz^T y1 ; dy1 = dz W1 + ds2 (residual)
     fork(1);
     if (int rc = linear_bwd_weight(dz, 4 * D, sv->y1, D, R, 4 * D, D, g->dw1, g->db1, wws, wws_bytes, 0, 0, sw)) return rc;
