@@ -1152,8 +1152,15 @@ __global__ __launch_bounds__(256, NR_X3_WGS) void gemm_x3_kernel(const GemmParam
     };
     auto fmma = [&](const Frags& f) {
         constexpr int TA[6] = {0, 2, 1, 0, 1, 0}, TB[6] = {2, 0, 1, 1, 0, 0};      // smallest products first
+#if NR_X3_EXP == 5
+        // diagnostic: every fragment read stays (kept alive below), one of the six MFMAs per product
 #pragma unroll
-        for (int t = (NR_X3_EXP == 2 ? 5 : 0); t < 6; ++t)
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int t = 0; t < 3; ++t) { asm volatile("" :: "v"(f.a[i][t])); asm volatile("" :: "v"(f.b[i][t])); }
+#endif
+#pragma unroll
+        for (int t = ((NR_X3_EXP == 2 || NR_X3_EXP == 5) ? 5 : 0); t < 6; ++t)
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -1186,8 +1193,16 @@ __global__ __launch_bounds__(256, NR_X3_WGS) void gemm_x3_kernel(const GemmParam
 #else
         Frags f0, f1;
         fload(f0, 0);
+#if NR_X3_EXP == 8
+        if (more && kt == kt_begin) gload(kt + 1);         // diagnostic: no global loads after the second k-tile
+#else
         if (more) gload(kt + 1);
+#endif
+#if NR_X3_EXP == 6
+        f1 = f0;                                           // diagnostic: half of the fragment reads, all MFMAs
+#else
         fload(f1, 1);
+#endif
         // the partner workgroup's wave on this SIMD is in its staging phase (a dense stream of independent VALU) while
         // this one multiplies: vector issue is arbitrated by priority, then AGE, so without a priority an older
         // staging wave starves a younger wave's MFMAs and the two phases add instead of overlapping
@@ -1199,7 +1214,17 @@ __global__ __launch_bounds__(256, NR_X3_WGS) void gemm_x3_kernel(const GemmParam
         if (kt - kt_begin < 6) X3_STAMP(3 + 4 * (kt - kt_begin));
         __syncthreads();                                  // everyone is done reading the single stage
         if (kt - kt_begin < 6) X3_STAMP(4 + 4 * (kt - kt_begin));
+#if NR_X3_EXP == 7
+        // diagnostic: no split and no LDS stores after the first k-tile (the loaded registers are kept alive)
+        if (more) {
+#pragma unroll
+            for (int i = 0; i < NA; ++i) asm volatile("" :: "v"(ra[i]));
+#pragma unroll
+            for (int i = 0; i < NB; ++i) asm volatile("" :: "v"(rb[i]));
+        }
+#else
         if (more) lstore();
+#endif
         if (kt - kt_begin < 6) X3_STAMP(5 + 4 * (kt - kt_begin));
         __syncthreads();
         if (kt - kt_begin < 6) X3_STAMP(6 + 4 * (kt - kt_begin));
