@@ -253,6 +253,17 @@ int nr_tfm_layer_packed_bwd_f32(const float* dy, const float* x, const int64_t* 
 int nr_query_pool_packed_fwd_f32(const float* key, const float* value, const int32_t* offs, int64_t R, const float* query, const int64_t* mask, int64_t nseq, int64_t S, int64_t D, float* out, float* prob, void* stream);
 int nr_query_pool_packed_bwd_f32(const float* key, const float* value, const int32_t* offs, int64_t R, const float* query, const float* prob, const float* dout, int64_t nseq, int64_t S, int64_t D, int tanh_key, float* dkeypre, float* dvalue, float* dquery, void* ws, size_t ws_bytes, void* stream);
 
+/* The same backward when the pooled vectors went to two consumers: sequences 0 .. split-1 take their gradient from dout0
+ * [split, D], the rest from dout1 [nseq - split, D] (a train step's candidate titles -> scoring, history titles -> user
+ * encoder, models/BaseModel.py:198-205): no concatenation of the two gradients is needed. */
+int nr_query_pool_packed_bwd_split_f32(const float* key, const float* value, const int32_t* offs, int64_t R, const float* query, const float* prob, const float* dout0, const float* dout1, int64_t split, int64_t nseq, int64_t S, int64_t D, int tanh_key, float* dkeypre, float* dvalue, float* dquery, void* ws, size_t ws_bytes, void* stream);
+/* Title tensors of one train step in one launch — replaces the reference's two host->device copies + two encoder calls
+ * (models/BaseModel.py:178-195) and the torch concatenations this package used before: block-major ids / mask
+ * [B*C + B*L, T] (all candidate titles, then all history titles) and keep [B*C + B*L] (1 for candidates; history slot
+ * (b,l): keep_mode 0 -> 1, 1 -> his_mask[b,l] != 0 (TfmUserEncoder), 2 -> l < sum(his_mask[b]) (RnnUserEncoder)). */
+int nr_assemble_titles(const int64_t* cdd_ids, const int64_t* his_ids, const int64_t* cdd_mask, const int64_t* his_attn_mask, const int64_t* his_mask,
+                       int keep_mode, int64_t B, int64_t C, int64_t L, int64_t T, int64_t* ids, int64_t* mask, int64_t* keep, void* stream);
+
 /* ---- bf16 build: building blocks (tensors in HBM as bf16 = raw uint16; no counterpart in the reference, whose closest
  * thing is torch.autocast over encoder.py:62-77) ---------------------------------------------------------
  * nr_cast_bf16: y = bf16(x), round to nearest even.

@@ -514,6 +514,29 @@ int nr_query_pool_packed_bwd_f32(const float* key, const float* value, const int
     return colsum(dq_part, D, nseq, (int)D, dquery, part, s);
 }
 
+int nr_assemble_titles(const int64_t* cdd_ids, const int64_t* his_ids, const int64_t* cdd_mask, const int64_t* his_attn_mask, const int64_t* his_mask,
+                       int keep_mode, int64_t B, int64_t C, int64_t L, int64_t T, int64_t* ids, int64_t* mask, int64_t* keep, void* stream) {
+    NR_CHECK_ARG(B >= 0 && C >= 0 && L >= 0 && T > 0 && B * (C + L) * T < (int64_t)1 << 40, "assemble_titles: bad sizes");
+    NR_CHECK_ARG(keep_mode >= 0 && keep_mode <= 2, "assemble_titles: keep_mode %d not in 0..2", keep_mode);
+    NR_CHECK_ARG(B * (C + L) == 0 || (ids && mask && keep), "assemble_titles: null output");
+    NR_CHECK_ARG(B * C == 0 || (cdd_ids && cdd_mask), "assemble_titles: null candidate tensors");
+    NR_CHECK_ARG(B * L == 0 || (his_ids && his_attn_mask && (keep_mode == 0 || his_mask)), "assemble_titles: null history tensors");
+    return assemble_titles(cdd_ids, his_ids, cdd_mask, his_attn_mask, his_mask, keep_mode, (int)B, (int)C, (int)L, (int)T, ids, mask, keep, S(stream));
+}
+
+int nr_query_pool_packed_bwd_split_f32(const float* key, const float* value, const int32_t* offs, int64_t rows, const float* query, const float* prob, const float* dout0, const float* dout1, int64_t split, int64_t nseq, int64_t Sq, int64_t D, int tanh_key, float* dkeypre, float* dvalue, float* dquery, void* ws, size_t ws_bytes, void* stream) {
+    NR_CHECK_ARG(nseq > 0 && Sq > 0 && D > 0 && rows >= 0 && rows <= nseq * Sq && split >= 0 && split <= nseq, "query_pool_packed_bwd_split: bad sizes");
+    NR_CHECK_ARG(key && value && offs && query && prob && dvalue && dquery && dkeypre && (split == 0 || dout0) && (split == nseq || dout1), "query_pool_packed_bwd_split: null pointer");
+    if (!ws || ws_bytes < nr_query_pool_bwd_ws_bytes(nseq, D)) { set_error("query_pool_packed_bwd_split: workspace too small"); return NR_ERR_WORKSPACE; }
+    char* cur = (char*)ws;
+    float* dq_part = bump(cur, (size_t)nseq * D);
+    float* part = bump(cur, (size_t)colsum_chunks(nseq) * D);
+    hipStream_t s = S(stream);
+    // (split == 0: everything reads dout1; the kernel's test is n >= split)
+    if (int rc = pool_bwd(key, value, query, prob, dout0 ? dout0 : dout1, dkeypre, dvalue, dq_part, nseq, (int)Sq, (int)D, tanh_key, 0, s, offs, rows, dout1, split)) return rc;
+    return colsum(dq_part, D, nseq, (int)D, dquery, part, s);
+}
+
 int nr_pack_plan(const int64_t* mask, const int64_t* title_keep, int64_t N, int64_t T, int32_t* offs, int32_t* info, void* stream) {
     NR_CHECK_ARG(N >= 0 && T > 0 && T <= 1024 && N * T < (int64_t)1 << 31, "pack_plan: bad sizes N=%lld T=%lld", (long long)N, (long long)T);
     NR_CHECK_ARG(offs && info && (N == 0 || mask), "pack_plan: null pointer");

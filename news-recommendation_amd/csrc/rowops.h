@@ -36,6 +36,8 @@ int ln_bwd(const float* dy, const float* sin, const float* mean, const float* rs
            float* dh, float* dgamma_part, float* dbeta_part, int64_t R, int D, DropoutCfg dc, hipStream_t s,
            unsigned short* dh_h = nullptr);     // dh_h: a bf16 copy of the dropped-branch gradient (dh, or ds when p == 0)
 int colsum_chunks(int64_t R);
+int assemble_titles(const int64_t* cdd_ids, const int64_t* his_ids, const int64_t* cdd_msk, const int64_t* his_msk, const int64_t* his_mask,
+                    int keep_mode, int B, int C, int L, int T, int64_t* ids, int64_t* msk, int64_t* keep, hipStream_t s);
 int pack_plan(const int64_t* mask, const int64_t* title_keep, int64_t N, int T, int* offs, int* info, hipStream_t s);
 int pack_ids(const int64_t* ids, const int* offs, int64_t N, int T, int64_t* ids_packed, int* row_map, hipStream_t s);
 int colsum(const float* in, int64_t ld, int64_t R, int N, float* out, float* part, hipStream_t s);

@@ -595,6 +595,47 @@ __global__ __launch_bounds__(256) void pack_ids_kernel(const int64_t* __restrict
     }
 }
 
+// ---- title tensors of one train step in ONE launch (models/BaseModel.py forward; reference BaseModel.py:178-195 copies the
+// candidate and history tensors to the device separately and encodes them in two calls).  Block-major layout: the B*C
+// candidate titles first, then the B*L history titles, so the news vectors of either group are one contiguous slice.
+//   ids / msk [B*C + B*L, T]; keep [B*C + B*L] (1 for candidates; history slot (b,l): keep_mode 1 -> his_mask[b,l] != 0,
+//   keep_mode 2 -> l < sum_l' his_mask[b,l'], keep_mode 0 -> 1)
+__global__ __launch_bounds__(256) void assemble_titles_kernel(const int64_t* __restrict__ cdd_ids, const int64_t* __restrict__ his_ids,
+                                                              const int64_t* __restrict__ cdd_msk, const int64_t* __restrict__ his_msk,
+                                                              const int64_t* __restrict__ his_mask, int keep_mode, int B, int C, int L, int T,
+                                                              int64_t* __restrict__ ids, int64_t* __restrict__ msk, int64_t* __restrict__ keep) {
+    const int64_t nc = (int64_t)B * C * T, total = nc + (int64_t)B * L * T;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const bool his = i >= nc;
+        const int64_t j = his ? i - nc : i;
+        ids[i] = his ? his_ids[j] : cdd_ids[j];
+        msk[i] = his ? his_msk[j] : cdd_msk[j];
+        if (j % T == 0) {
+            const int64_t title = i / T;
+            int64_t k = 1;
+            if (his && keep_mode != 0) {
+                const int64_t slot = j / T;                   // b * L + l
+                if (keep_mode == 1) k = his_mask[slot] != 0;
+                else {
+                    const int64_t b = slot / L, l = slot - b * L;
+                    int64_t len = 0;
+                    for (int t = 0; t < L; ++t) len += his_mask[b * L + t];
+                    k = l < len;
+                }
+            }
+            keep[title] = k;
+        }
+    }
+}
+int assemble_titles(const int64_t* cdd_ids, const int64_t* his_ids, const int64_t* cdd_msk, const int64_t* his_msk, const int64_t* his_mask,
+                    int keep_mode, int B, int C, int L, int T, int64_t* ids, int64_t* msk, int64_t* keep, hipStream_t s) {
+    const int64_t total = (int64_t)B * (C + L) * T;
+    if (total == 0) return NR_OK;
+    const int grid = (int)std::min<int64_t>(cdiv(total, 256), 2048);
+    hipLaunchKernelGGL(assemble_titles_kernel, dim3(grid), dim3(256), 0, s, cdd_ids, his_ids, cdd_msk, his_msk, his_mask, keep_mode, B, C, L, T, ids, msk, keep);
+    return check_launch("assemble_titles");
+}
+
 int pack_plan(const int64_t* mask, const int64_t* title_keep, int64_t N, int T, int* offs, int* info, hipStream_t s) {
     // info[1]: stage 1 raises it on a mask row that is not prefix-shaped, stage 2 turns it into the "all rows are" flag
     if (hipMemsetAsync(info, 0, 2 * sizeof(int), s) != hipSuccess) { set_error("pack_plan: memset failed"); return NR_ERR_LAUNCH; }

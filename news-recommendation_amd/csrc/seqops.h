@@ -35,7 +35,7 @@ int pool_fwd(const float* key, const float* value, const float* table, const int
              const int* offs = nullptr, int64_t rows = 0);       // offs: packed sequences (rows = their total)
 int pool_bwd(const float* key, const float* value, const float* query, const float* prob, const float* dout, float* dkeypre,
              float* dvalue, float* dq_part, int64_t nseq, int S, int D, int tanh_key, int key_is_value, hipStream_t s,
-             const int* offs = nullptr, int64_t rows = 0);
+             const int* offs = nullptr, int64_t rows = 0, const float* dout1 = nullptr, int64_t split = 0);   // dout1: gradient of sequences split ..
 int score_fwd(const float* cdd, const float* table, const int64_t* idx, int64_t nrows, const float* user, const int64_t* label,
               float* logits, float* loss_b, int64_t B, int C, int D, hipStream_t s);
 int score_bwd(const float* cdd, const float* user, const int64_t* label, const float* logits, const float* grad_out,

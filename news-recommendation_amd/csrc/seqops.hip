@@ -169,7 +169,7 @@ __global__ __launch_bounds__(256) void pool_bwd_kernel(const float* __restrict__
                                                        const float* __restrict__ dout, float* __restrict__ dkeypre,
                                                        float* __restrict__ dvalue, float* __restrict__ dq_part,
                                                        int64_t nseq, int S, int D, int tanh_key, int key_is_value,
-                                                       const int* __restrict__ offs) {
+                                                       const int* __restrict__ offs, const float* __restrict__ dout1, int64_t split) {
     __shared__ float sdp[64 * SL];
     __shared__ __attribute__((aligned(16))) float part[WPB][IT * 256];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -184,7 +184,8 @@ __global__ __launch_bounds__(256) void pool_bwd_kernel(const float* __restrict__
     }
     float4 q[IT], g[IT];
     load_row<IT>(q, query, D, lane);
-    load_row<IT>(g, dout + n * (int64_t)D, D, lane);
+    // (two upstream gradients: sequences 0 .. split-1 read dout, the rest dout1 — candidates | history of a train step)
+    load_row<IT>(g, (dout1 && n >= split) ? dout1 + (n - split) * (int64_t)D : dout + n * (int64_t)D, D, lane);
     const float sq = sqrtf((float)D);
     const float p = lane < Sn ? prob[n * S + lane] : 0.f;
     const float p2 = (SL == 2 && lane + 64 < Sn) ? prob[n * S + lane + 64] : 0.f;
@@ -410,12 +411,12 @@ int pool_fwd(const float* key, const float* value, const float* table, const int
 
 int pool_bwd(const float* key, const float* value, const float* query, const float* prob, const float* dout, float* dkeypre,
              float* dvalue, float* dq_part, int64_t nseq, int S, int D, int tanh_key, int key_is_value, hipStream_t s,
-             const int* offs, int64_t rows) {
+             const int* offs, int64_t rows, const float* dout1, int64_t split) {
     if (nseq == 0) return NR_OK;
     if (int rc = check_seq_dims("pooling bwd", S, D, 128)) return rc;
     ProfScope prof(FAM_POOL, s, (double)(offs ? rows : nseq * S) * (4.0 * D * 4));
     const dim3 grid((unsigned)nseq);
-    NR_POOL_DISPATCH(pool_bwd_kernel, grid, key, value, query, prob, dout, dkeypre, dvalue, dq_part, nseq, S, D, tanh_key, key_is_value, offs);
+    NR_POOL_DISPATCH(pool_bwd_kernel, grid, key, value, query, prob, dout, dkeypre, dvalue, dq_part, nseq, S, D, tanh_key, key_is_value, offs, dout1, split);
     return check_launch("pool_bwd");
 }
 

@@ -181,7 +181,23 @@ class TwoTowerBaseModel(BaseModel):
         return self.userEncoder(his_news_embedding, his_mask=his_mask)
 
     def _train_inputs(self, x):
-        """the tensors forward() works on: (C, ids [B,C+L,T], masks, his_mask, keep, pending pack plan)"""
+        """the tensors forward() works on: (block, C, ids, masks, his_mask, keep, pending pack plan).
+        block = True: block-major title tensors [B*C + B*L, T] — every candidate title, then every history title —
+        assembled with their keep flags by ONE launch (ops.assemble_titles) for news encoders whose news_vectors can hand
+        the two groups out separately (`split`); otherwise batch-major [B, C+L, T] through torch concatenations."""
+        his_mask = x["his_mask"].to(self.device)
+        begin = getattr(self.newsEncoder, "plan_begin", None)
+        if "cdd_token_id" in x and begin is not None and getattr(self, "block_major", True) and torch.device(self.device).type == "cuda":
+            cdd_ids = x["cdd_token_id"].to(self.device)
+            C = cdd_ids.shape[1]
+            has_keep = hasattr(self.userEncoder, "history_keep")
+            mode = getattr(self.userEncoder, "history_keep_mode", None) if has_keep else 0
+            if mode is not None:
+                ids, masks, keep = ops.assemble_titles(cdd_ids, x["his_token_id"].to(self.device), x["cdd_attn_mask"].to(self.device),
+                                                       x["his_attn_mask"].to(self.device), his_mask, mode)
+                if not has_keep:
+                    keep = None
+                return True, C, ids, masks, his_mask, keep, begin(ids, masks, keep)
         if "cdd_token_id" in x:
             cdd_ids = x["cdd_token_id"].to(self.device)
             C = cdd_ids.shape[1]
@@ -190,15 +206,13 @@ class TwoTowerBaseModel(BaseModel):
         else:                               # indices only: one gather for candidates + history
             C = x["cdd_idx"].shape[1]
             ids, masks = self._tokens({"all_idx": torch.cat([x["cdd_idx"], x["his_idx"]], dim=1)}, "all")
-        his_mask = x["his_mask"].to(self.device)
         keep = None
         if hasattr(self.userEncoder, "history_keep"):
             # history slots the user encoder masks out cannot reach the loss: as masked keys / skipped GRU steps their
             # weight is exactly 0 and so is every gradient into them -> those titles are not encoded at all
             keep = torch.cat([torch.ones_like(his_mask[:, :1]).expand(-1, C), self.userEncoder.history_keep(his_mask)], dim=1)
-        begin = getattr(self.newsEncoder, "plan_begin", None)
         pending = begin(ids, masks, keep) if begin is not None else None
-        return C, ids, masks, his_mask, keep, pending
+        return False, C, ids, masks, his_mask, keep, pending
 
     def plan_ahead(self, x):
         """optional look-ahead for a training loop that already holds its NEXT batch: assemble that batch's title tensors
@@ -209,12 +223,17 @@ class TwoTowerBaseModel(BaseModel):
     def forward(self, x):
         """mean softmax-CE of the clicked candidate (label 0) among 1+K candidates (reference
         BaseModel.py:198-205).  Titles are encoded independently of each other, so the candidate and
-        history titles of the batch go through the news encoder as ONE [B, C+L, T] call (the reference
-        makes two calls; per-title results are identical) and are split afterwards."""
+        history titles of the batch go through the news encoder as ONE call (the reference makes two;
+        per-title results are identical) and are split afterwards."""
         ahead, self._ahead = getattr(self, "_ahead", None), None
-        C, ids, masks, his_mask, keep, pending = ahead[1] if ahead is not None and ahead[0] is x else self._train_inputs(x)
-        news = self._news_vectors(ids, masks, keep, pending)
-        cdd_news_embedding, his_news_embedding = ops.split_titles(news, C)
+        block, C, ids, masks, his_mask, keep, pending = ahead[1] if ahead is not None and ahead[0] is x else self._train_inputs(x)
+        if block:
+            B, L = his_mask.shape
+            cdd, his = self.newsEncoder.news_vectors(ids, masks, keep, pending, split=B * C)
+            cdd_news_embedding, his_news_embedding = cdd.view(B, C, -1), his.view(B, L, -1)
+        else:
+            news = self._news_vectors(ids, masks, keep, pending)
+            cdd_news_embedding, his_news_embedding = ops.split_titles(news, C)
         user_embedding = self.userEncoder(his_news_embedding, his_mask=his_mask)
         labels = x["label"].to(self.device)
         loss, _ = ops.score_cross_entropy(cdd_news_embedding, user_embedding, labels)

@@ -112,22 +112,28 @@ class TfmNewsEncoder(BaseNewsEncoder):
         T = token_id.shape[-1]
         return ops.pack_titles_begin(attn_mask.reshape(-1, T), title_keep) if self.packable(T) else None
 
-    def news_vectors(self, token_id, attn_mask, title_keep=None, pending=None):
+    def news_vectors(self, token_id, attn_mask, title_keep=None, pending=None, split=None):
         """the news vectors alone, for callers that drop token_embedding (TwoTowerBaseModel.forward / encode_news):
         same numbers as forward()[1], computed over the real token rows only (packed title tokens, include/newsrec_hip.h)
         whenever the masks are prefix-shaped and T <= 32; otherwise through forward().  title_keep [...] 0/1 marks
-        titles whose vector the caller never uses (masked history slots): they are not encoded and come back as zeros."""
+        titles whose vector the caller never uses (masked history slots): they are not encoded and come back as zeros.
+        split (token_id must be [N, T]): return (vectors[:split], vectors[split:]) — two slices of one buffer, no copy,
+        and the backward reads the two gradients where they are."""
         shape = token_id.shape
         T = shape[-1]
         mask = attn_mask.reshape(-1, T)
         packed = ops.pack_titles(token_id.reshape(-1, T), mask, title_keep, pending) if self.packable(T) else None
         if packed is None:
-            return self.forward(token_id, attn_mask)[1]
+            news = self.forward(token_id, attn_mask)[1]
+            return news if split is None else ops.split_rows(news.reshape(-1, news.shape[-1]), split)
         ids_p, plan = packed
         emb = ops.embedding(self.embedding.weight, ids_p, self.embedding.padding_idx)        # [rows, E]
         tok = self.transformer(emb, attention_mask=mask, plan=plan)
+        if split is not None and 0 < split < mask.shape[0]:
+            a, b, _ = ops.project_and_pool(tok, self.newsProject.weight, self.newsProject.bias, self.news_query, mask, plan=plan, split=split)
+            return a, b
         news, _ = ops.project_and_pool(tok, self.newsProject.weight, self.newsProject.bias, self.news_query, mask, plan=plan)
-        return news.view(*shape[:-1], -1)
+        return news.view(*shape[:-1], -1) if split is None else ops.split_rows(news, split)
 
     def packable(self, T):
         return T <= 32 and self.transformer.hidden_dim // self.transformer.head_num <= 64 and not getattr(self, "no_packing", False)
@@ -249,25 +255,28 @@ class AllBertNewsEncoder(BaseNewsEncoder):
         T = token_id.shape[-1]
         return ops.pack_titles_begin(attn_mask.reshape(-1, T), title_keep) if self.packable(T) else None
 
-    def news_vectors(self, token_id, attn_mask, title_keep=None, pending=None):
+    def news_vectors(self, token_id, attn_mask, title_keep=None, pending=None, split=None):
         """the [CLS] vectors alone, over the real token rows only (packed title tokens, include/newsrec_hip.h): HF's masked
         keys are excluded outright, so a padded position reaches neither another token nor the [CLS] row.  Same numbers as
-        forward()[1]; titles `title_keep` marks 0 are not encoded."""
+        forward()[1]; titles `title_keep` marks 0 are not encoded.  split (token_id [N, T]): (vectors[:split], vectors[split:])."""
         shape = token_id.shape
         T = shape[-1]
         mask = attn_mask.reshape(-1, T)
         packed = ops.pack_titles(token_id.reshape(-1, T), mask, title_keep, pending) if self.packable(T) else None
         if packed is None:
-            return self.forward(token_id, attn_mask)[1]
-        ids_p, plan = packed
-        tok = self.plm(ids_p, mask, plan=plan)
-        return ops.first_rows(tok, plan).view(*shape[:-1], -1)
+            news = self.forward(token_id, attn_mask)[1]
+        else:
+            ids_p, plan = packed
+            tok = self.plm(ids_p, mask, plan=plan)
+            news = ops.first_rows(tok, plan).view(*shape[:-1], -1)
+        return news if split is None else ops.split_rows(news.reshape(-1, news.shape[-1]), split)
 
 
 class RnnUserEncoder(BaseUserEncoder):
     """final GRU state over the clicked-news vectors (the default -ue of main.twotower).  ``self.rnn`` is an
     nn.GRU used as a parameter container only (reference key names rnn.weight_ih_l0 …); the recurrence runs
     in the HIP library (input half as one MFMA GEMM, 2 small launches per step, no lens.cpu() sync)."""
+    history_keep_mode = 2      # nr_assemble_titles: slot index < history length (the same rule as history_keep below)
 
     @staticmethod
     def history_keep(his_mask):
@@ -317,6 +326,8 @@ class AttnUserEncoder(BaseUserEncoder):
 
 
 class TfmUserEncoder(BaseUserEncoder):
+    history_keep_mode = 1      # nr_assemble_titles: his_mask != 0 (the same rule as history_keep below)
+
     @staticmethod
     def history_keep(his_mask):
         """[B,L] 0/1: his_mask == 0 slots are masked keys of the layer and of the pooling (weight exactly 0, reference

@@ -151,6 +151,26 @@ def embedding(table, ids, padding_idx=PAD_ID):
     return _Embedding.apply(_f32(table, "embedding.weight"), _i64(ids, "token_id"), padding_idx)
 
 
+# ----------------------------------------------------------------------------- title tensors of a train step
+def assemble_titles(cdd_ids, his_ids, cdd_mask, his_attn_mask, his_mask, keep_mode):
+    """block-major title tensors of one train step in one launch (nr_assemble_titles): ids / mask [B*C + B*L, T] — every
+    candidate title, then every history title — and keep [B*C + B*L] (keep_mode 0: all ones, 1: his_mask != 0, 2: slot
+    index < history length).  Bit-exact copies; no autograd."""
+    cdd_ids, his_ids = _i64(cdd_ids, "cdd_token_id"), _i64(his_ids, "his_token_id")
+    cdd_mask, his_attn_mask, his_mask = _i64(cdd_mask, "cdd_attn_mask"), _i64(his_attn_mask, "his_attn_mask"), _i64(his_mask, "his_mask")
+    B, Cn, T = cdd_ids.shape
+    L = his_ids.shape[1]
+    if his_ids.shape != (B, L, T) or cdd_mask.shape != cdd_ids.shape or his_attn_mask.shape != his_ids.shape or his_mask.shape != (B, L):
+        raise NewsrecError("assemble_titles: inconsistent batch shapes")
+    n = B * (Cn + L)
+    ids = torch.empty(n, T, dtype=torch.int64, device=cdd_ids.device)
+    msk = torch.empty(n, T, dtype=torch.int64, device=cdd_ids.device)
+    keep = torch.empty(n, dtype=torch.int64, device=cdd_ids.device)
+    check(lib().nr_assemble_titles(_p(cdd_ids), _p(his_ids), _p(cdd_mask), _p(his_attn_mask), _p(his_mask), int(keep_mode), B, Cn, L, T,
+                                   _p(ids), _p(msk), _p(keep), _stream()), "nr_assemble_titles")
+    return ids, msk, keep
+
+
 # ----------------------------------------------------------------------------- packed title tokens
 class PackPlan:
     """row layout of N titles with the padded positions removed (include/newsrec_hip.h, "packed title tokens"):
@@ -815,10 +835,12 @@ def first_rows(x, plan):
 
 # ----------------------------------------------------------------------------- projection + query pooling
 class _ProjPool(torch.autograd.Function):
-    """out = softmax(q . tanh(x W^T + b)^T / sqrt(D) + mask) . x  — encoder.py:57,141,326."""
+    """out = softmax(q . tanh(x W^T + b)^T / sqrt(D) + mask) . x  — encoder.py:57,141,326.
+    split (packed layout only): the pooled vectors are handed out as TWO tensors, sequences [0, split) and [split, nseq)
+    (slices of one buffer: no copy), and the backward reads their two gradients where they are (no concatenation)."""
 
     @staticmethod
-    def forward(ctx, x, w, b, query, mask, plan):
+    def forward(ctx, x, w, b, query, mask, plan, split):
         nseq, S = mask.shape
         D = x.shape[-1]
         x2 = x.view(-1, D)
@@ -832,40 +854,59 @@ class _ProjPool(torch.autograd.Function):
             check(lib().nr_query_pool_packed_fwd_f32(_p(key), _p(x), _p(plan.offs), plan.rows, _p(query), _p(mask), nseq, S, D,
                                                      _p(out), _p(prob), _stream()), "nr_query_pool_packed_fwd_f32")
         ctx.save_for_backward(x, w, query, key, prob)
-        ctx.plan, ctx.dims = plan, (nseq, S, D)
+        ctx.plan, ctx.dims, ctx.split = plan, (nseq, S, D), split
         ctx.mark_non_differentiable(prob)
         ctx.set_materialize_grads(False)        # no zero tensor for the output nobody differentiates
-        return out, prob
+        if split is None:
+            return out, prob
+        return out[:split], out[split:], prob
 
     @staticmethod
-    def backward(ctx, g, _gprob):
-        if g is None:
-            return None, None, None, None, None, None
+    def backward(ctx, *grads):
+        split = ctx.split
+        if split is None:
+            g, g1 = grads[0], None
+            if g is None:
+                return (None,) * 7
+        else:
+            g, g1 = grads[0], grads[1]
+            if g is None and g1 is None:
+                return (None,) * 7
         x, w, query, key, prob = ctx.saved_tensors
         nseq, S, D = ctx.dims
         plan = ctx.plan
         R = nseq * S if plan is None else plan.rows
-        g = _f32(g, "grad")
         L = lib()
-        dkeypre = torch.empty(R, D, dtype=torch.float32, device=g.device)
-        dvalue = torch.empty(R, D, dtype=torch.float32, device=g.device)
+        dkeypre = torch.empty(R, D, dtype=torch.float32, device=x.device)
+        dvalue = torch.empty(R, D, dtype=torch.float32, device=x.device)
         dq = torch.empty_like(query)
-        ws = _ws(L.nr_query_pool_bwd_ws_bytes(nseq, D), g.device)
-        if plan is None:
+        ws = _ws(L.nr_query_pool_bwd_ws_bytes(nseq, D), x.device)
+        if split is not None:
+            g = _f32(g, "grad") if g is not None else torch.zeros(split, D, dtype=torch.float32, device=x.device)
+            g1 = _f32(g1, "grad") if g1 is not None else torch.zeros(nseq - split, D, dtype=torch.float32, device=x.device)
+            check(L.nr_query_pool_packed_bwd_split_f32(_p(key), _p(x), _p(plan.offs), R, _p(query), _p(prob), _p(g), _p(g1), split, nseq, S, D, 1,
+                                                       _p(dkeypre), _p(dvalue), _p(dq), _p(ws), ws.numel() * 4, _stream()),
+                  "nr_query_pool_packed_bwd_split_f32")
+        elif plan is None:
+            g = _f32(g, "grad")
             check(L.nr_query_pool_bwd_f32(_p(key), _p(x), _p(query), _p(prob), _p(g), nseq, S, D, 1, 0, _p(dkeypre), _p(dvalue),
                                           _p(dq), _p(ws), ws.numel() * 4, _stream()), "nr_query_pool_bwd_f32")
         else:
+            g = _f32(g, "grad")
             check(L.nr_query_pool_packed_bwd_f32(_p(key), _p(x), _p(plan.offs), R, _p(query), _p(prob), _p(g), nseq, S, D, 1,
                                                  _p(dkeypre), _p(dvalue), _p(dq), _p(ws), ws.numel() * 4, _stream()),
                   "nr_query_pool_packed_bwd_f32")
         dx, dw, db = linear_bwd_both(dkeypre, w, x.view(-1, D), True, True, 1, dvalue)          # dx = dkeypre W + dvalue
-        return dx.view(x.shape), dw, db, dq, None, None
+        return dx.view(x.shape), dw, db, dq, None, None, None
 
 
-def project_and_pool(x, w, b, query, mask, plan=None):
-    """x [nseq,S,D] (or packed [rows,D] with a PackPlan) -> (pooled [nseq,D], prob [nseq,S])."""
+def project_and_pool(x, w, b, query, mask, plan=None, split=None):
+    """x [nseq,S,D] (or packed [rows,D] with a PackPlan) -> (pooled [nseq,D], prob [nseq,S]); with `split` (packed layout):
+    (pooled[:split], pooled[split:], prob), two slices of one buffer whose gradients the backward reads in place."""
+    if split is not None and (plan is None or not 0 < int(split) < mask.shape[0]):
+        raise NewsrecError("project_and_pool: split needs the packed layout and 0 < split < number of sequences")
     return _ProjPool.apply(_f32(x, "x"), _f32(w, "project.weight"), _f32(b, "project.bias"), _f32(query, "query"),
-                           _i64(mask, "mask"), plan)
+                           _i64(mask, "mask"), plan, None if split is None else int(split))
 
 
 class _Pool(torch.autograd.Function):
@@ -1009,6 +1050,35 @@ class _SplitTitles(torch.autograd.Function):
 
 def split_titles(news, C):
     return _SplitTitles.apply(news, int(C))
+
+
+class _SplitRows(torch.autograd.Function):
+    """x [N, D] -> (x[:split], x[split:]) as two fresh tensors; the backward is one concatenation (two autograd slices
+    would cost two zero-filled [N, D] buffers, two copies and an add)."""
+
+    @staticmethod
+    def forward(ctx, x, split):
+        ctx.split, ctx.shape = split, x.shape
+        ctx.set_materialize_grads(False)
+        return x[:split].clone(), x[split:].clone()
+
+    @staticmethod
+    def backward(ctx, g0, g1):
+        if g0 is None and g1 is None:
+            return None, None
+        N, D = ctx.shape
+        ref = g0 if g0 is not None else g1
+        if g0 is None:
+            g0 = ref.new_zeros(ctx.split, D)
+        if g1 is None:
+            g1 = ref.new_zeros(N - ctx.split, D)
+        return torch.cat([g0, g1], dim=0), None
+
+
+def split_rows(x, split):
+    if x.dim() != 2 or not 0 <= int(split) <= x.shape[0]:
+        raise NewsrecError(f"split_rows: x {tuple(x.shape)} / split {split}")
+    return _SplitRows.apply(x, int(split))
 
 
 # ----------------------------------------------------------------------------- scoring (+ cross entropy)

@@ -90,10 +90,12 @@ class FlatGradSync(torch.nn.Module):
     ahead of other nodes), so it travels while the scatter-add runs; the table part follows in sync().  Without the hook
     (CPU tests, torch modules) sync() issues both, one after the other: same result."""
 
-    def __init__(self, module, world_size=None, late_suffixes=LATE_SUFFIXES):
+    def __init__(self, module, world_size=None, late_suffixes=LATE_SUFFIXES, always_reduce=False):
         super().__init__()
         self.module = module
         self.world = world_size if world_size is not None else (dist.get_world_size() if dist.is_initialized() else 1)
+        # always_reduce: issue the collectives with a single rank too (the RCCL smoke run of a one-GPU box)
+        self._reduce = self.world > 1 or (always_reduce and dist.is_initialized())
         named = [(n, p) for n, p in module.named_parameters() if p.requires_grad]
         late = [(n, p) for n, p in named if n.endswith(tuple(late_suffixes))]
         early = [(n, p) for n, p in named if not n.endswith(tuple(late_suffixes))]
@@ -112,7 +114,7 @@ class FlatGradSync(torch.nn.Module):
             self.n_early = off
         self.flat_early, self.flat_late = self.flat[:self.n_early], self.flat[self.n_early:]
         self._early_done, self._works, self._dirty = False, [], False
-        if self.world > 1:                       # replicas start from rank 0's weights (and buffers), like DDP
+        if self._reduce:                         # replicas start from rank 0's weights (and buffers), like DDP
             with torch.no_grad():
                 for t in list(module.parameters()) + list(module.buffers()):
                     broadcast_(t.data, 0)
@@ -175,7 +177,7 @@ class FlatGradSync(torch.nn.Module):
             return
         self._early_done = True
         self._pack(0, self.n_early_params)
-        if self.world > 1 and self.n_early:
+        if self._reduce and self.n_early:
             self._works.append(all_reduce_async(self.flat_early))
 
     @torch.no_grad()
@@ -186,7 +188,7 @@ class FlatGradSync(torch.nn.Module):
                                "all-reduce started during the first one; call zero_grad() before every backward")
         self.sync_early()
         self._pack(self.n_early_params, len(self.params))
-        if self.world <= 1:
+        if not self._reduce:
             return
         if self.flat_late.numel():
             self._works.append(all_reduce_async(self.flat_late))

@@ -824,3 +824,31 @@ def test_out_of_range_index_is_reported(ops):
             with pytest.raises(NewsrecError, match="out of range"):
                 ops.check_indices(name)
             ops.check_indices(name)                            # reading the flag cleared it
+
+
+@pytest.mark.parametrize("mode", [0, 1, 2])
+def test_assemble_titles_bit_exact(mode):
+    """nr_assemble_titles: block-major ids / masks (candidates, then history) and the keep flags of the three user-encoder
+    rules, against torch.cat of the same tensors (reference BaseModel.py:178-195 moves them separately)."""
+    from newsrec_hip import ops
+    g = torch.Generator().manual_seed(5)
+    B, Cn, L, T = 7, 5, 50, 32
+    cdd = torch.randint(0, 30522, (B, Cn, T), generator=g).cuda()
+    his = torch.randint(0, 30522, (B, L, T), generator=g).cuda()
+    cm = (torch.rand(B, Cn, T, generator=g) < 0.6).long().cuda()
+    hm = (torch.rand(B, L, T, generator=g) < 0.6).long().cuda()
+    his_mask = (torch.rand(B, L, generator=g) < 0.5).long().cuda()
+    his_mask[2] = 0
+    his_mask[4] = 1
+    ids, msk, keep = ops.assemble_titles(cdd, his, cm, hm, his_mask, mode)
+    assert torch.equal(ids, torch.cat([cdd.reshape(-1, T), his.reshape(-1, T)]))
+    assert torch.equal(msk, torch.cat([cm.reshape(-1, T), hm.reshape(-1, T)]))
+    if mode == 0:
+        hk = torch.ones_like(his_mask)
+    elif mode == 1:
+        hk = (his_mask != 0).long()
+    else:
+        hk = (torch.arange(L, device="cuda")[None, :] < his_mask.sum(1, keepdim=True)).long()
+    assert torch.equal(keep, torch.cat([torch.ones(B * Cn, dtype=torch.int64, device="cuda"), hk.reshape(-1)]))
+    with pytest.raises(ops.NewsrecError):
+        ops.assemble_titles(cdd, his[:, :, :16], cm, hm, his_mask, mode)

@@ -363,6 +363,35 @@ def test_forward_skips_dead_history_titles_exactly(ue):
         assert (g1[n] - g0[n]).abs().max().item() <= GRAD_TOL * g0[n].abs().max().item() + 3e-6 * gscale, n
 
 
+@pytest.mark.parametrize("ue", ["tfm", "rnn", "attn"])
+def test_block_major_titles_equal_batch_major(ue):
+    """TwoTowerBaseModel.forward assembles block-major title tensors (all candidate titles, then all history titles:
+    ops.assemble_titles, one launch) and takes the two groups of news vectors as two slices of the pooling output; the
+    batch-major path ([B, C+L, T] by torch.cat + split_titles, `block_major = False`) computes the same loss and gradients.
+    Dropout off (eval mode): the keep bits are indexed by a title's position in the call, which differs between the two."""
+    meta = dict(V=30522, E=300, D=300, H=12, T=32, L=50, K=4, B=16, Nn=3000)
+    model, mgr = build_model(meta, "tfm", ue)
+    g = torch.Generator().manual_seed(77)
+    ids, msk = synth_news_table(g, meta["Nn"], meta["T"], meta["V"])
+    X = {k: v.cuda() for k, v in synth_batch(g, meta["B"], meta["K"] + 1, meta["L"], meta["Nn"], ids, msk).items()}
+    X["his_mask"][3] = 0                                   # a user without history
+    model = model.cuda().eval()
+    runs = []
+    for block in (False, True):
+        model.block_major = block
+        model.zero_grad(set_to_none=True)
+        blk = model._train_inputs(X)[0]
+        assert blk == block
+        loss = model(X)
+        loss.backward()
+        runs.append((loss.detach().clone(), {n: p_.grad.detach().clone() for n, p_ in model.named_parameters()}))
+    (l0, g0), (l1, g1) = runs
+    assert abs(l0.item() - l1.item()) <= 1e-6 * abs(l0.item())
+    gscale = max(float(v.abs().max()) for v in g0.values())
+    for n in g0:
+        assert (g1[n] - g0[n]).abs().max().item() <= GRAD_TOL * g0[n].abs().max().item() + 3e-6 * gscale, n
+
+
 def test_plan_ahead_changes_nothing():
     """TwoTowerBaseModel.plan_ahead(x) (the pack plan of the next batch, queued a step early as Manager._train does)
     followed by forward(x): loss and gradients are bit-equal to forward(x) alone; a plan started for another batch is
