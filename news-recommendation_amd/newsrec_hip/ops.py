@@ -496,13 +496,15 @@ _TFM_ORDER = ("wq", "bq", "wk", "bk", "wv", "bv", "wo", "bo", "ln1_g", "ln1_b", 
 
 
 def _carve(device, sizes):
-    """one allocation, 256-B aligned views (floats)."""
+    """one allocation, 256-B aligned pieces (floats): (buffer, device address of every piece; 0-sized pieces -> None).
+    Addresses, not views: a dozen tensor slices per layer call cost the host more than the layer's C call."""
     offs, tot = [], 0
     for s in sizes:
         offs.append(tot)
         tot += (int(s) + 63) // 64 * 64
     buf = torch.empty(max(tot, 64), dtype=torch.float32, device=device)
-    return buf, [buf[o:o + int(s)] for o, s in zip(offs, sizes)]
+    base = buf.data_ptr()
+    return buf, [base + 4 * o if s else None for o, s in zip(offs, sizes)]
 
 
 class _TFMLayer(torch.autograd.Function):
@@ -514,11 +516,10 @@ class _TFMLayer(torch.autograd.Function):
         train = any(ctx.needs_input_grad)       # False under no_grad / eval-only calls
         sizes = [3 * D * D, 3 * D, R * 3 * D, R * D, R * D, R * D, R * 4 * D if train else 0, R * 4 * D, R * D,
                  4 * R if train else 0, N * H * S if train else 0, N * H * S if train else 0]
-        buf, (wqkv, bqkv, qkv, cx, s1, y1, z, a, s2, stats, rmax, rsum) = _carve(x.device, sizes)
+        buf, ptrs = _carve(x.device, sizes)           # wqkv bqkv qkv ctx s1 y1 z a s2 stats rmax rsum
         y = torch.empty_like(x)
         W = TfmWeights(*[_p(t) for t in params])
-        SV = TfmSaved(_p(wqkv), _p(bqkv), _p(qkv), _p(cx), _p(s1), _p(y1), _p(z) if train else None, _p(a), _p(s2),
-                      _p(stats) if train else None, _p(rmax) if train else None, _p(rsum) if train else None)
+        SV = TfmSaved(*ptrs)
         if plan is None:
             check(lib().nr_tfm_layer_fwd_f32(_p(x), _p(mask), N, S, D, H, C.byref(W), p, seed, site, mask_mode, C.byref(SV),
                                             _p(y), _stream()), "nr_tfm_layer_fwd_f32")
@@ -540,7 +541,8 @@ class _TFMLayer(torch.autograd.Function):
         for s in sizes:
             offs.append(tot)
             tot += (int(s) + 63) // 64 * 64
-        ptrs = [buf.data_ptr() + 4 * o for o in offs]
+        base = buf.data_ptr()
+        ptrs = [base + 4 * o if s else None for o, s in zip(offs, sizes)]
         W = TfmWeights(*[_p(t) for t in params])
         SV = TfmSaved(*ptrs)
         # packed q|k|v gradient: three contiguous views, handed out as the three parameters' grads

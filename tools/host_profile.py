@@ -13,7 +13,8 @@ model = model.cuda().train()
 opt, _ = model.get_optimizer(mgr, 1000)
 g = torch.Generator().manual_seed(1000)
 ids, msk = bench.synth_table(g, bench.NEWS_TRAIN)
-batches = [{k: v.cuda() for k, v in bench.synth_train_batch(g, 32, bench.NEWS_TRAIN, ids, msk).items()} for _ in range(8)]
+B = int(sys.argv[2]) if len(sys.argv) > 2 else 32
+batches = [{k: v.cuda() for k, v in bench.synth_train_batch(g, B, bench.NEWS_TRAIN, ids, msk).items()} for _ in range(8)]
 
 def step(i):
     opt.zero_grad(set_to_none=True)
