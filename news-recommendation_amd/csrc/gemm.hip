@@ -1740,6 +1740,18 @@ static bool tall_tile(int M, int N, int K) {
 static bool short_tile(int M) { return cdiv(M, 64) * 64 < cdiv(M, 128) * 128; }
 static int dw_tile_rows(int M, int N, int K) { return tall_tile(M, N, K) ? 320 : (short_tile(M) ? 64 : 128); }
 
+// outputs that the split kernel's 16 384-element tiles pad badly (300 x 300: 384 x 384 = 1.64x the work) and 64 x 64 tiles
+// do not (320 x 320 = 1.14x): the small-tile kernel takes them whatever the grid size
+static bool x3_prefers_small(int M, int N) {
+    static const bool off = getenv("NR_X3_SMALL_PREF") && atoi(getenv("NR_X3_SMALL_PREF")) == 0;      // A/B switch for tools
+    if (off) return false;
+    const int shape = x3_tile_shape(M, N);
+    const int bm[3] = {256, 128, 64}, bn[3] = {64, 128, 256};
+    const int64_t big = (int64_t)cdiv(M, bm[shape]) * bm[shape] * cdiv(N, bn[shape]) * bn[shape];
+    const int64_t small = (int64_t)cdiv(M, 64) * 64 * cdiv(N, 64) * 64;
+    return 10 * big > 13 * small;
+}
+
 size_t gemm_workspace_bytes(int M, int N, int ksplit) {
     return ksplit > 1 ? (size_t)ksplit * M * N * sizeof(float) : 0;
 }
@@ -1754,7 +1766,7 @@ int choose_ksplit(int M, int N, int K) {
         const int tiles = cdiv(M, bm[shape]) * cdiv(N, bn[shape]);
         const int kt = cdiv(K, BK);
         const int ks = std::min(cdiv(target, tiles), kt / 8);
-        if (ks >= 2 && tiles * ks >= 200) return ks;
+        if (ks >= 2 && tiles * ks >= 200 && !x3_prefers_small(M, N)) return ks;
         // small-tile split kernel: 64 x 64 tiles, 64-deep k-tiles; ~1.5 workgroups per CU, slices of >= 4 k-tiles
         static const int target_s = getenv("NR_X3S_KS_WGS") ? atoi(getenv("NR_X3S_KS_WGS")) : 384;
         const int tiles_s = cdiv(M, 64) * cdiv(N, 64);
@@ -1801,7 +1813,8 @@ int gemm_f32(GemmParams p, bool a_kc, bool b_kc, float* workspace, size_t ws_byt
     const int x3_shape = env_shape >= 0 ? env_shape : x3_tile_shape(p.M, p.N);
     const int x3_bm[3] = {256, 128, 64}, x3_bn[3] = {64, 128, 256};
     const bool x3 = fast && g_gemm_compute.load() == 2 && p.K >= 64 && (a_kc || !b_kc) &&
-                    (int64_t)cdiv(p.M, x3_bm[x3_shape]) * cdiv(p.N, x3_bn[x3_shape]) * p.ksplit >= env_minwg;
+                    (int64_t)cdiv(p.M, x3_bm[x3_shape]) * cdiv(p.N, x3_bn[x3_shape]) * p.ksplit >= env_minwg &&
+                    !(p.ksplit > 1 && x3_prefers_small(p.M, p.N));
     const bool x3s = !x3 && fast && g_gemm_compute.load() == 2 && (a_kc || !b_kc) && x3s_eligible(p.M, p.N, p.K, p.ksplit);
     ProfScope prof(x3 ? FAM_GEMM_SPLIT : FAM_GEMM, s, 2.0 * p.M * p.N * p.K);
     p.tune = g_tune[TUNE_X3_PRIO].load() ? 1 : 0;
