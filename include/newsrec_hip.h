@@ -276,6 +276,15 @@ int nr_cast_bf16(const float* x, int64_t n, uint16_t* y, void* stream);
 int nr_transpose_bf16(const void* src, int src_is_bf16, int64_t R, int64_t C, int64_t ld, uint16_t* dst, int64_t Rp, void* stream);
 size_t nr_gemm_nt_bf16_ws_bytes(int64_t M, int64_t N, int64_t K, int split_k);
 int nr_gemm_nt_bf16(const uint16_t* A, const uint16_t* B, const float* bias, int64_t M, int64_t N, int64_t K, int act, float* C, uint16_t* Ch, uint16_t* zh, int split_k, void* ws, size_t ws_bytes, void* stream);
+/* nr_gemm_bf16 (round 3): the same product with either operand REDUCTION-MAJOR, as the backward finds them in memory
+ * (no counterpart in the reference: torch.autocast transposes inside its BLAS calls):
+ *   a_rm = 0: A(m,k) = A[m*lda + k]      a_rm = 1: A(m,k) = A[k*lda + m]   (dY of dW = dY^T X; needs M % 8 == 0)
+ *   b_rm = 0: B(n,k) = B[n*ldb + k]      b_rm = 1: B(n,k) = B[k*ldb + n]   (X of dW, the weight of dX = dY W; N % 8 == 0)
+ * (a_rm, b_rm) = (0,0) | (0,1) | (1,1); K % 64 == 0 unless both operands are reduction-major (their rows past K read
+ * zeros: any K).  Tiles go to LDS as they lie in memory and the matrix-core fragments are taken with transposed LDS
+ * reads (ds_read_b64_tr_b16), so the layer backward makes no transposed copies.  Pitches in elements, multiples of 8;
+ * 16-byte aligned bases.  Outputs / act / split_k as nr_gemm_nt_bf16. */
+int nr_gemm_bf16(const uint16_t* A, int a_rm, int64_t lda, const uint16_t* B, int b_rm, int64_t ldb, const float* bias, int64_t M, int64_t N, int64_t K, int act, float* C, uint16_t* Ch, uint16_t* zh, int split_k, void* ws, size_t ws_bytes, void* stream);
 
 /* ---- the transformer layer of the bf16 build (AllBertNewsEncoder, encoder.py:62-77, parity bar 1e-2) ----
  * Same layer, same argument meaning as nr_tfm_layer_{fwd,bwd}_f32; every GEMM operand (x, qkv, ctx, LN1 output,
@@ -288,8 +297,9 @@ typedef struct {
     float *s1, *y1, *s2;                                /* f32 [R,D]: drop(dense)+x, LN1 output (forward only), drop(dense)+y1 */
     float *stats, *row_max, *row_sum;                   /* [4,R], [N,H,S], [N,H,S] */
     uint16_t *w_h;                                      /* bf16 wqkv | wo | w1 | w2: 12 D^2 elements */
-    uint16_t *aT_h;                                     /* bf16 [4D, Rp], Rp = R rounded up to 64: the GELU output transposed (may be NULL:
-                                                           the backward then transposes a_h itself) */
+    uint16_t *aT_h;                                     /* unused since round 3 (kept for the layout of the struct; pass NULL): the
+                                                           backward's dW products read a_h and the other row-major tensors as
+                                                           reduction-major operands (nr_gemm_bf16), no transposed copies */
 } nr_tfm_saved_bf16;
 /* offs / row_map: NULL for the dense [N,S,D] layout (R = N*S), or the packed-title-token plan of nr_pack_plan / nr_pack_ids (R rows). */
 int nr_tfm_layer_fwd_bf16(const float* x, const int64_t* mask, const int32_t* offs, const int32_t* row_map, int64_t N, int64_t S, int64_t R, int64_t D, int64_t H, const nr_tfm_weights* w, float p_drop, uint64_t seed, uint32_t site_base, int mask_mode, nr_tfm_saved_bf16* saved, float* y, void* stream);

@@ -620,6 +620,17 @@ int nr_gemm_nt_bf16(const uint16_t* A, const uint16_t* B, const float* bias, int
     return gemm_h(p, (float*)ws, ws_bytes, S(stream));
 }
 
+int nr_gemm_bf16(const uint16_t* A, int a_rm, int64_t lda, const uint16_t* B, int b_rm, int64_t ldb, const float* bias, int64_t M, int64_t N, int64_t K, int act, float* C, uint16_t* Ch, uint16_t* zh, int split_k, void* ws, size_t ws_bytes, void* stream) {
+    NR_CHECK_ARG(M >= 0 && N > 0 && K > 0, "gemm_bf16: bad sizes");
+    NR_CHECK_ARG(act >= 0 && act <= 3, "gemm_bf16: act %d not in 0..3", act);
+    NR_CHECK_ARG(lda >= (a_rm ? M : K) && ldb >= (b_rm ? N : K), "gemm_bf16: pitch smaller than the row it strides");
+    GemmHParams p;
+    p.A = A; p.lda = lda; p.a_rm = a_rm ? 1 : 0; p.B = B; p.ldb = ldb; p.b_rm = b_rm ? 1 : 0; p.M = (int)M; p.N = (int)N; p.K = (int)K;
+    p.C = C; p.ldc = N; p.Ch = Ch; p.ldch = N; p.bias = bias; p.epi = act; p.out2h = zh; p.ldout2h = N;
+    if (split_k) p.ksplit = choose_ksplit_h(p.M, p.N, p.K);
+    return gemm_h(p, (float*)ws, ws_bytes, S(stream));
+}
+
 int nr_adam_step_f32(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, double lr, double beta1, double beta2, double eps, int64_t step, void* stream) {
     NR_CHECK_ARG(n >= 0 && step >= 1, "adam_step: bad sizes");
     NR_CHECK_ARG(n == 0 || (param && grad && exp_avg && exp_avg_sq), "adam_step: null pointer");
@@ -871,10 +882,20 @@ int nr_tfm_layer_fwd_bf16(const float* x, const int64_t* mask, const int32_t* of
     if (int rc = mhsa_fwd_mfma_h(sv->qkv_h, mask, sv->ctx_h, sv->row_max, sv->row_sum, N, (int)Sq, (int)H, (int)(D / H), DCP(DCA(p_drop, seed, site_base, mask_mode), offs, nullptr), s)) return rc;
     if (int rc = gemm_nt(sv->ctx_h, D, wo_h, D, R, D, D, w->bo, EPI_NONE, sv->s1, nullptr, nullptr, nullptr, nullptr, s)) return rc;
     if (int rc = ln_fwd(sv->s1, x, w->ln1_g, w->ln1_b, sv->y1, sv->s1, mean1, rstd1, R, (int)D, 1e-12f, DCP(DC(p_drop, seed, site_base + 1), nullptr, row_map), s, 0, sv->y1_h)) return rc;
-    // (the GELU output also leaves transposed, [4D, Rp]: the dW2 product of the backward takes it as is)
-    if (int rc = gemm_nt(sv->y1_h, D, w1_h, D, R, 4 * D, D, w->b1, EPI_GELU, nullptr, sv->a_h, nullptr, nullptr, sv->z_h, s, sv->aT_h, sv->aT_h ? (R + 63) / 64 * 64 : 0)) return rc;
+    // (sv->aT_h, the transposed GELU output of round 2, is no longer written: the backward's dW2 product reads a_h as it is)
+    if (int rc = gemm_nt(sv->y1_h, D, w1_h, D, R, 4 * D, D, w->b1, EPI_GELU, nullptr, sv->a_h, nullptr, nullptr, sv->z_h, s)) return rc;
     if (int rc = gemm_nt(sv->a_h, 4 * D, w2_h, 4 * D, R, D, 4 * D, w->b2, EPI_NONE, sv->s2, nullptr, nullptr, nullptr, nullptr, s)) return rc;
     return ln_fwd(sv->s2, sv->y1, w->ln2_g, w->ln2_b, y, sv->s2, mean2, rstd2, R, (int)D, 1e-12f, DCP(DC(p_drop, seed, site_base + 2), nullptr, row_map), s);
+}
+
+// dW [N,K] = dY^T X straight from the row-major bf16 tensors dy [R,N], x [R,K]: both operands reduction-major (transposed
+// LDS reads in gemm_h_kernel), any R, no transposed copies (split over the reduction, slabs in ws)
+static int gemm_dw_rm(const unsigned short* dy, const unsigned short* x, int64_t N, int64_t K, int64_t R, float* dw, float* ws, size_t ws_bytes, hipStream_t s) {
+    GemmHParams p;
+    p.A = dy; p.lda = N; p.a_rm = 1; p.B = x; p.ldb = K; p.b_rm = 1; p.M = (int)N; p.N = (int)K; p.K = (int)R;
+    p.C = dw; p.ldc = K;
+    p.ksplit = choose_ksplit_h(p.M, p.N, p.K);
+    return gemm_h(p, ws, ws_bytes, s);
 }
 
 static size_t dw_ws_h(int64_t N, int64_t K, int64_t Rp) { return pad256b(gemm_h_workspace_bytes((int)N, (int)K, choose_ksplit_h((int)N, (int)K, (int)Rp))); }
@@ -883,9 +904,8 @@ size_t nr_tfm_layer_bwd_bf16_ws_bytes(int64_t R, int64_t D) {
     const int64_t Rp = (R + 63) / 64 * 64;
     size_t b = 0;
     b += 5 * pad256((size_t)R * D);                                        // ds2 dh2 dy1 ds1 dh1 (f32)
-    b += 2 * pad256b((size_t)R * D * 2);                                   // dh_h, dctx_h
-    b += pad256b((size_t)D * Rp * 2) + pad256b((size_t)4 * D * Rp * 2);    // dhT, actT
-    b += pad256b((size_t)R * 4 * D * 2) + pad256b((size_t)4 * D * Rp * 2); // dz_h, dzT (also dqkvT)
+    b += 3 * pad256b((size_t)R * D * 2);                                   // dh2_h, dh1_h, dctx_h
+    b += pad256b((size_t)R * 4 * D * 2);                                   // dz_h
     b += pad256b((size_t)R * 3 * D * 2);                                   // dqkv_h
     b += pad256b((size_t)4 * D * D * 2);                                   // transposed bf16 weight
     b += nr_layernorm_bwd_ws_bytes(R, D);
@@ -912,12 +932,10 @@ int nr_tfm_layer_bwd_bf16(const float* dy, const int64_t* mask, const int32_t* o
     float* dy1 = bump(cur, (size_t)R * D);
     float* ds1 = bump(cur, (size_t)R * D);
     float* dh1 = p_drop > 0.f ? bump(cur, (size_t)R * D) : ds1;
-    unsigned short* dh_h = bumph(cur, (size_t)R * D);
+    unsigned short* dh2_h = bumph(cur, (size_t)R * D);
+    unsigned short* dh1_h = bumph(cur, (size_t)R * D);          // (not dh2_h again: the second stream may still be reading that one)
     unsigned short* dctx_h = bumph(cur, (size_t)R * D);
-    unsigned short* dhT = bumph(cur, (size_t)D * Rp);
-    unsigned short* actT = bumph(cur, (size_t)4 * D * Rp);
     unsigned short* dz_h = bumph(cur, (size_t)R * 4 * D);
-    unsigned short* dzT = bumph(cur, (size_t)4 * D * Rp);
     unsigned short* dqkv_h = bumph(cur, (size_t)R * 3 * D);
     unsigned short* wT = bumph(cur, (size_t)4 * DD);
     char* lnws = cur; cur += nr_layernorm_bwd_ws_bytes(R, D);
@@ -925,52 +943,43 @@ int nr_tfm_layer_bwd_bf16(const float* dy, const int64_t* mask, const int32_t* o
     float* slabs = reinterpret_cast<float*>(cur);
     const size_t slab_bytes = ws_bytes - (size_t)(cur - (char*)ws);
     const float* mean1 = sv->stats, *rstd1 = sv->stats + R, *mean2 = sv->stats + 2 * R, *rstd2 = sv->stats + 3 * R;
-    // Everything that only serves a weight / bias gradient (operand transposes, the dW product and its slab sum, the
-    // column sums) runs on the second stream, in order, so dhT / actT / dzT / cpart / slabs are reused there without
-    // hazards; the main stream keeps LayerNorm, the weight transposes, the dX products and the attention backward.
+    // Everything that only serves a weight / bias gradient (the dW product and its slab sum, the column sums) runs on the
+    // second stream, in order, so cpart / slabs are reused there without hazards; the main stream keeps LayerNorm, the weight
+    // transposes, the dX products and the attention backward.  Round 3: the dW products read dY and X where they lie
+    // (row-major [R, .] = reduction-major operands, gemm_dw_rm): the eight transposed copies per layer and the transposed
+    // second outputs of two GEMM epilogues (aT, dzT: 2 x R x 4D x 2 bytes each) are gone.
     SideStream* ss = R >= SIDE_MIN_ROWS ? side_stream() : nullptr;
     SideUse su(ss, s);
     hipStream_t sw = su.stream();
     auto fork = [&](int i) { su.fork(i); sw = su.stream(); };
 
     // LN2 <- dy
-    if (int rc = layernorm_bwd(dy, sv->s2, mean2, rstd2, w->ln2_g, R, (int)D, DCP(DC(p_drop, seed, site_base + 2), nullptr, row_map), ds2, p_drop > 0.f ? dh2 : nullptr, g->dln2_g, g->dln2_b, lnws, s, dh_h)) return rc;
+    if (int rc = layernorm_bwd(dy, sv->s2, mean2, rstd2, w->ln2_g, R, (int)D, DCP(DC(p_drop, seed, site_base + 2), nullptr, row_map), ds2, p_drop > 0.f ? dh2 : nullptr, g->dln2_g, g->dln2_b, lnws, s, dh2_h)) return rc;
     // FFN2: dW2 [D,4D] = dh2^T a ; db2 ; dz = (dh2 W2) * gelu'(z)
     fork(0);
-    if (int rc = transpose_bf16(dh2, 0, D, R, D, dhT, Rp, sw)) return rc;
-    const unsigned short* aT = sv->aT_h;
-    if (!aT) {
-        if (int rc = transpose_bf16(sv->a_h, 1, 4 * D, R, 4 * D, actT, Rp, sw)) return rc;
-        aT = actT;
-    }
-    if (int rc = gemm_dw(dhT, aT, D, 4 * D, Rp, g->dw2, slabs, slab_bytes, sw)) return rc;
+    if (int rc = gemm_dw_rm(dh2_h, sv->a_h, D, 4 * D, R, g->dw2, slabs, slab_bytes, sw)) return rc;
     if (int rc = colsum(dh2, D, R, (int)D, g->db2, cpart, sw)) return rc;
     if (int rc = transpose_bf16(w->w2, 0, 4 * D, D, 4 * D, wT, D, s)) return rc;                       // [D,4D] -> [4D,D]
-    if (int rc = gemm_nt(dh_h, D, wT, D, R, 4 * D, D, nullptr, EPI_MUL_GELU_GRAD, nullptr, dz_h, nullptr, sv->z_h, nullptr, s, dzT, Rp)) return rc;
-    // FFN1: dW1 [4D,D] = dz^T y1 ; db1 ; dy1 = dz W1 + ds2   (dz^T came out of the product above)
+    if (int rc = gemm_nt(dh2_h, D, wT, D, R, 4 * D, D, nullptr, EPI_MUL_GELU_GRAD, nullptr, dz_h, nullptr, sv->z_h, nullptr, s)) return rc;
+    // FFN1: dW1 [4D,D] = dz^T y1 ; db1 ; dy1 = dz W1 + ds2
     fork(1);
-    if (int rc = transpose_bf16(sv->y1_h, 1, D, R, D, actT, Rp, sw)) return rc;
-    if (int rc = gemm_dw(dzT, actT, 4 * D, D, Rp, g->dw1, slabs, slab_bytes, sw)) return rc;
+    if (int rc = gemm_dw_rm(dz_h, sv->y1_h, 4 * D, D, R, g->dw1, slabs, slab_bytes, sw)) return rc;
     if (int rc = colsum_h(dz_h, 4 * D, R, (int)(4 * D), g->db1, cpart, sw)) return rc;
     if (int rc = transpose_bf16(w->w1, 0, D, 4 * D, D, wT, 4 * D, s)) return rc;                       // [4D,D] -> [D,4D]
     if (int rc = gemm_nt(dz_h, 4 * D, wT, 4 * D, R, D, 4 * D, nullptr, EPI_ADD_AUX, dy1, nullptr, ds2, nullptr, nullptr, s)) return rc;
     // LN1
-    if (int rc = layernorm_bwd(dy1, sv->s1, mean1, rstd1, w->ln1_g, R, (int)D, DCP(DC(p_drop, seed, site_base + 1), nullptr, row_map), ds1, p_drop > 0.f ? dh1 : nullptr, g->dln1_g, g->dln1_b, lnws, s, dh_h)) return rc;
+    if (int rc = layernorm_bwd(dy1, sv->s1, mean1, rstd1, w->ln1_g, R, (int)D, DCP(DC(p_drop, seed, site_base + 1), nullptr, row_map), ds1, p_drop > 0.f ? dh1 : nullptr, g->dln1_g, g->dln1_b, lnws, s, dh1_h)) return rc;
     // attention output projection: dWo = dh1^T ctx ; dbo ; dctx = dh1 Wo
     fork(2);
-    if (int rc = transpose_bf16(dh1, 0, D, R, D, dhT, Rp, sw)) return rc;
-    if (int rc = transpose_bf16(sv->ctx_h, 1, D, R, D, actT, Rp, sw)) return rc;
-    if (int rc = gemm_dw(dhT, actT, D, D, Rp, g->dwo, slabs, slab_bytes, sw)) return rc;
+    if (int rc = gemm_dw_rm(dh1_h, sv->ctx_h, D, D, R, g->dwo, slabs, slab_bytes, sw)) return rc;
     if (int rc = colsum(dh1, D, R, (int)D, g->dbo, cpart, sw)) return rc;
     if (int rc = transpose_bf16(w->wo, 0, D, D, D, wT, D, s)) return rc;
-    if (int rc = gemm_nt(dh_h, D, wT, D, R, D, D, nullptr, EPI_NONE, nullptr, dctx_h, nullptr, nullptr, nullptr, s)) return rc;
+    if (int rc = gemm_nt(dh1_h, D, wT, D, R, D, D, nullptr, EPI_NONE, nullptr, dctx_h, nullptr, nullptr, nullptr, s)) return rc;
     // attention core
     if (int rc = mhsa_bwd_mfma_h(sv->qkv_h, mask, dctx_h, sv->row_max, sv->row_sum, dqkv_h, N, (int)Sq, (int)H, (int)(D / H), DCP(DCA(p_drop, seed, site_base, mask_mode), offs, nullptr), s)) return rc;
     // QKV projection: dWqkv [3D,D] = dqkv^T x ; dbqkv ; dx = dqkv Wqkv + ds1
     fork(3);
-    if (int rc = transpose_bf16(dqkv_h, 1, 3 * D, R, 3 * D, dzT, Rp, sw)) return rc;
-    if (int rc = transpose_bf16(sv->x_h, 1, D, R, D, actT, Rp, sw)) return rc;
-    if (int rc = gemm_dw(dzT, actT, 3 * D, D, Rp, g->dwq, slabs, slab_bytes, sw)) return rc;
+    if (int rc = gemm_dw_rm(dqkv_h, sv->x_h, 3 * D, D, R, g->dwq, slabs, slab_bytes, sw)) return rc;
     if (int rc = colsum_h(dqkv_h, 3 * D, R, (int)(3 * D), g->dbq, cpart, sw)) return rc;
     if (int rc = transpose_bf16(w->wq, 0, D, 3 * D, D, wT, 3 * D, s)) return rc;                       // [3D,D] -> [D,3D]
     if (int rc = gemm_nt(dqkv_h, 3 * D, wT, 3 * D, R, D, 3 * D, nullptr, EPI_ADD_AUX, dx, nullptr, ds1, nullptr, nullptr, s)) return rc;

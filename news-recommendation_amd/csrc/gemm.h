@@ -51,8 +51,10 @@ int get_tuning(int key);
 struct GemmHParams {
     const unsigned short* A = nullptr;
     const unsigned short* B = nullptr;
-    int M = 0, N = 0, K = 0;                     // K a multiple of 64
+    int M = 0, N = 0, K = 0;                     // K a multiple of 64 unless both operands are reduction-major
     int64_t lda = 0, ldb = 0;
+    int a_rm = 0, b_rm = 0;                      // reduction-major operand: A(m,k) = A[k*lda + m] / B(n,k) = B[k*ldb + n] (M / N % 8 == 0)
+    const unsigned short* zero = nullptr;        // 256 bytes of zeros (set by gemm_h): what reduction rows past K read
     float* C = nullptr;
     int64_t ldc = 0;
     unsigned short* Ch = nullptr;

@@ -20,6 +20,7 @@
 #include "common.h"
 #include "gemm.h"
 #include <cstdlib>
+#include <mutex>
 
 namespace nr {
 
@@ -43,6 +44,34 @@ __device__ __forceinline__ uint32_t pack2(float lo, float hi) {
 }
 __device__ __forceinline__ float bf2f(unsigned short v) { return __builtin_bit_cast(float, (uint32_t)v << 16); }
 
+// 256 bytes of zeros per GPU: the source of a reduction-major tile's k-rows past K
+static __device__ __attribute__((aligned(256))) unsigned short g_zero_page[128];
+static const unsigned short* zero_page_ptr() {
+    static std::mutex mu;
+    static const unsigned short* per_dev[64];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+    std::lock_guard<std::mutex> lk(mu);
+    if (!per_dev[dev]) {
+        unsigned short* ptr = nullptr;
+        if (hipGetSymbolAddress(reinterpret_cast<void**>(&ptr), HIP_SYMBOL(g_zero_page)) == hipSuccess && ptr) per_dev[dev] = ptr;
+        else (void)hipGetLastError();
+    }
+    return per_dev[dev];
+}
+
+// Reduction-major operands (A_RM: A[k][m], B_RM: B[k][n] — dY and X of dW = dY^T X, the weight of dX = dY W) need no
+// transposed copy in HBM: their 64 (k) x 128 tile goes to LDS as it lies in memory (256-byte rows, 16-byte chunk ch of
+// row r at chunk ch ^ (((r & 3) << 2) | ((r >> 2) & 3)), applied to the SOURCE address as for the k-contiguous image) and
+// the MFMA fragments come out of it through ds_read_b64_tr_b16: per 16-lane group a 4 (k) x 16 (column) block, delivered
+// column-major, lane 4q+p supplying the address of row q, columns 4p .. 4p+3 (measured lane map: tools/tr_probe.hip) —
+// two reads make the eight consecutive k of one lane's 32x32x16 operand.  k-rows past K are read from a page of zeros,
+// so the reduction length need not be padded.
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ int rm_swz(int row) { return ((row & 3) << 2) | ((row >> 2) & 3); }
+
+template <bool A_RM, bool B_RM>
 __global__ __launch_bounds__(256, 2) void gemm_h_kernel(const GemmHParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char hsm[];
     const int tid = threadIdx.x;
@@ -65,41 +94,65 @@ __global__ __launch_bounds__(256, 2) void gemm_h_kernel(const GemmHParams p) {
     const int tm = bid / tiles_n, tn = bid - tm * tiles_n;
     const int m0 = tm * HM, n0 = tn * HN;
 
-    const int kt_total = p.K / HK;
+    const int kt_total = (p.K + HK - 1) / HK;
     const int kt_per = (kt_total + p.ksplit - 1) / p.ksplit;
     const int kt_begin = ks * kt_per;
     const int kt_end = min(kt_total, kt_begin + kt_per);
 
     // per-lane source pointers of this wave's 4 + 4 fills per k-tile: fill c covers tile rows 8c .. 8c+7,
     // lane -> row 8c + (lane >> 3), LDS chunk lane & 7 = logical chunk ^ ((row >> 1) & 7)
+    // (reduction-major: fill c covers k-rows 4c .. 4c+3 of 256 B, lane -> k-row 4c + (lane >> 4), LDS chunk lane & 15 =
+    // logical chunk ^ rm_swz(k-row); columns past the edge read the last valid chunk and are never stored)
     const unsigned short* ga[4];
     const unsigned short* gb[4];
+    const unsigned short* zsrc = p.zero + (lane & 15) * 8;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const int c = wid + 4 * j;
-        const int row = 8 * c + (lane >> 3);
-        const int chunk = (lane & 7) ^ ((row >> 1) & 7);
-        const int ra = min(m0 + row, p.M - 1), rb = min(n0 + row, p.N - 1);
-        ga[j] = p.A + (int64_t)ra * p.lda + chunk * 8;
-        gb[j] = p.B + (int64_t)rb * p.ldb + chunk * 8;
+        if (A_RM) {
+            const int krow = 4 * c + (lane >> 4);
+            const int col = min(m0 + (((lane & 15) ^ rm_swz(krow)) << 3), p.M - 8);
+            ga[j] = p.A + (int64_t)krow * p.lda + col;
+        } else {
+            const int row = 8 * c + (lane >> 3);
+            const int chunk = (lane & 7) ^ ((row >> 1) & 7);
+            ga[j] = p.A + (int64_t)min(m0 + row, p.M - 1) * p.lda + chunk * 8;
+        }
+        if (B_RM) {
+            const int krow = 4 * c + (lane >> 4);
+            const int col = min(n0 + (((lane & 15) ^ rm_swz(krow)) << 3), p.N - 8);
+            gb[j] = p.B + (int64_t)krow * p.ldb + col;
+        } else {
+            const int row = 8 * c + (lane >> 3);
+            const int chunk = (lane & 7) ^ ((row >> 1) & 7);
+            gb[j] = p.B + (int64_t)min(n0 + row, p.N - 1) * p.ldb + chunk * 8;
+        }
     }
-    auto stage = [&](int buf, int kt) {
+    // Only the LAST k-tile of a reduction-major operand can hold rows past K: `tail` selects the zero page for those lanes there, so the
+    // loop proper carries no predicate (a per-lane pointer select in the loop became exec-masked branches around every fill).
+    auto stage = [&](int buf, int kt, bool tail) {
         unsigned char* As = hsm + buf * H_STAGE_BYTES;
         unsigned char* Bs = As + H_TILE_BYTES;
         const int k0 = kt * HK;
+        const int64_t ka = A_RM ? (int64_t)k0 * p.lda : (int64_t)k0, kb = B_RM ? (int64_t)k0 * p.ldb : (int64_t)k0;      // wave-uniform
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int c = wid + 4 * j;
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(ga[j] + k0),
+            const unsigned short* src = ga[j] + ka;
+            if (A_RM && tail && k0 + 4 * c + (lane >> 4) >= p.K) src = zsrc;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                              (__attribute__((address_space(3))) void*)(As + c * 1024), 16, 0, 0);
         }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int c = wid + 4 * j;
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gb[j] + k0),
+            const unsigned short* src = gb[j] + kb;
+            if (B_RM && tail && k0 + 4 * c + (lane >> 4) >= p.K) src = zsrc;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                              (__attribute__((address_space(3))) void*)(Bs + c * 1024), 16, 0, 0);
         }
     };
+    const bool ragged = (A_RM || B_RM) && (p.K % HK) != 0;         // then the last k-tile of the whole product is partial
 
     f32x16 acc[2][2];
 #pragma unroll
@@ -112,31 +165,73 @@ __global__ __launch_bounds__(256, 2) void gemm_h_kernel(const GemmHParams p) {
     // fragment addresses: row (wr*64 + i*32 + l31) of A / (wc*64 + j*32 + l31) of B, logical chunk 2*s + h of k-step s
     const int sw = (l31 >> 1) & 7;                        // tile-row offsets are multiples of 16: swizzle depends on l31 only
     const int arow = (wr * 64 + l31) * 128, brow = (wc * 64 + l31) * 128;
+    // transposed reads of a reduction-major tile: byte offset of this lane's address for 32-column block i, k-quad t of a
+    // k-step (k-step s adds 16 rows = 4096 bytes; rm_swz of row 16s + 8h + 4t + q does not depend on s)
+    int tra[2][2], trb[2][2];
+    {
+        const int g = lane >> 4, q = (lane & 15) >> 2, pq = lane & 3;
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const int row = 8 * (g >> 1) + 4 * t + q;
+            const int sz = rm_swz(row);
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int ca = wr * 64 + i * 32 + 16 * (g & 1) + 4 * pq, cb = wc * 64 + i * 32 + 16 * (g & 1) + 4 * pq;
+                tra[i][t] = row * 256 + (((ca >> 3) ^ sz) << 4) + (ca & 7) * 2;
+                trb[i][t] = row * 256 + (((cb >> 3) ^ sz) << 4) + (cb & 7) * 2;
+            }
+        }
+    }
+    auto tr8 = [](const unsigned char* base, int o0, int o1) {
+        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(base + o0));
+        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(base + o1));
+        const s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        return __builtin_bit_cast(bf16x8, v);
+    };
+    // fragments of k-step s+1 are requested before the MFMAs of k-step s are issued (two register sets): a wave's LDS
+    // latency then hides behind its own matrix work instead of only behind the partner workgroup's
     auto compute = [&](int buf) {
         const unsigned char* As = hsm + buf * H_STAGE_BYTES;
         const unsigned char* Bs = As + H_TILE_BYTES;
+        bf16x8 fa[2][2], fb[2][2];
+        auto frags = [&](int s, bf16x8 (&a)[2], bf16x8 (&b)[2]) {
+            const int co = ((2 * s + h) ^ sw) << 4;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                if (A_RM) a[i] = tr8(As + s * 4096, tra[i][0], tra[i][1]);
+                else      a[i] = *reinterpret_cast<const bf16x8*>(As + arow + i * 32 * 128 + co);
+            }
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                if (B_RM) b[j] = tr8(Bs + s * 4096, trb[j][0], trb[j][1]);
+                else      b[j] = *reinterpret_cast<const bf16x8*>(Bs + brow + j * 32 * 128 + co);
+            }
+        };
+        frags(0, fa[0], fb[0]);
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
-            const int co = ((2 * s + h) ^ sw) << 4;
-            bf16x8 fa[2], fb[2];
-#pragma unroll
-            for (int i = 0; i < 2; ++i) fa[i] = *reinterpret_cast<const bf16x8*>(As + arow + i * 32 * 128 + co);
-#pragma unroll
-            for (int j = 0; j < 2; ++j) fb[j] = *reinterpret_cast<const bf16x8*>(Bs + brow + j * 32 * 128 + co);
+            if (s + 1 < 4) frags(s + 1, fa[(s + 1) & 1], fb[(s + 1) & 1]);
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
                 for (int j = 0; j < 2; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[s & 1][i], fb[s & 1][j], acc[i][j], 0, 0, 0);
         }
     };
 
     if (kt_begin < kt_end) {
-        stage(0, kt_begin);
+        const bool last_is_tail = ragged && kt_end == kt_total;
+        stage(0, kt_begin, last_is_tail && kt_begin == kt_end - 1);
         __syncthreads();                                   // drains the fills (vmcnt(0)) and publishes them
         int cur = 0;
-        for (int kt = kt_begin; kt < kt_end - 1; ++kt) {
-            stage(cur ^ 1, kt + 1);                        // next tile flies while this one is multiplied
+        for (int kt = kt_begin; kt < kt_end - 2; ++kt) {
+            stage(cur ^ 1, kt + 1, false);                 // next tile flies while this one is multiplied
+            compute(cur);
+            __syncthreads();
+            cur ^= 1;
+        }
+        if (kt_end - kt_begin >= 2) {
+            stage(cur ^ 1, kt_end - 1, last_is_tail);
             compute(cur);
             __syncthreads();
             cur ^= 1;
@@ -267,7 +362,7 @@ int choose_ksplit_h(int M, int N, int K) {
     static const int forced = getenv("NR_GEMM_H_KSPLIT") ? atoi(getenv("NR_GEMM_H_KSPLIT")) : 0;     // tools/gemm_h_bench.py sweep
     if (forced > 0) return std::max(1, std::min(forced, K / HK));
     const int tiles = cdiv(M, HM) * cdiv(N, HN);
-    const int kt = K / HK;
+    const int kt = (K + HK - 1) / HK;
     if (tiles >= 256 || kt < 8) return 1;
     // one full round of the chip (256 CUs x 2 resident workgroups) and no more: swept on MI355X at the BERT-base dW
     // shapes (K = 14 080): 144 tiles x 3 = 432 workgroups 712 TFLOP/s (x2 545, x4 577, x13 504); 108 tiles x 4 667; 36 x 13 417-730
@@ -278,14 +373,21 @@ int choose_ksplit_h(int M, int N, int K) {
 
 size_t gemm_h_workspace_bytes(int M, int N, int ksplit) { return ksplit > 1 ? (size_t)ksplit * M * N * sizeof(float) : 0; }
 
-bool gemm_h_supported(int M, int N, int K) { return M >= 1 && N >= 1 && K >= HK && K % HK == 0; }
+bool gemm_h_supported(int M, int N, int K) { return M >= 1 && N >= 1 && K >= HK && K % HK == 0; }       // the NT form
 
 int gemm_h(GemmHParams p, float* workspace, size_t ws_bytes, hipStream_t s) {
     NR_CHECK_ARG(p.M >= 0 && p.N >= 0 && p.K >= 0, "gemm_h: negative dims");
     if (p.M == 0 || p.N == 0) return NR_OK;
     NR_CHECK_ARG(p.A && p.B && (p.C || p.Ch), "gemm_h: null operand");
     NR_CHECK_ARG(!p.ChT || (p.ldcht % 64 == 0 && p.ldcht >= p.M && (reinterpret_cast<uintptr_t>(p.ChT) & 15) == 0), "gemm_h: transposed output needs a 64-multiple pitch >= M");
-    NR_UNSUPPORTED(!gemm_h_supported(p.M, p.N, p.K), "gemm_h: K=%d must be a positive multiple of %d", p.K, HK);
+    NR_UNSUPPORTED(p.a_rm && !p.b_rm, "gemm_h: layout (A reduction-major, B k-contiguous) not built");
+    // a k-contiguous operand is read 64 k at a time with no edge handling; reduction-major tiles take their rows past K from zeros
+    NR_UNSUPPORTED(p.K < 1 || ((!p.a_rm || !p.b_rm) && p.K % HK != 0), "gemm_h: K=%d must be a positive multiple of %d unless both operands are reduction-major", p.K, HK);
+    NR_UNSUPPORTED((p.a_rm && (p.M % 8 != 0 || p.M < 8)) || (p.b_rm && (p.N % 8 != 0 || p.N < 8)), "gemm_h: a reduction-major operand needs M / N to be a multiple of 8");
+    if (p.a_rm || p.b_rm) {
+        p.zero = zero_page_ptr();
+        if (!p.zero) { set_error("gemm_h: the per-GPU zero page is unavailable (hipGetSymbolAddress failed)"); return NR_ERR_LAUNCH; }
+    }
     auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
     // 16-byte epilogue accesses need aligned bases and row pitches; anything else takes the element-wise path
     p.vec = (!p.C || (p.ldc % 4 == 0 && al16(p.C))) && (!p.Ch || (p.ldch % 8 == 0 && al16(p.Ch))) && (!p.aux || (p.ldaux % 4 == 0 && al16(p.aux))) &&
@@ -304,9 +406,16 @@ int gemm_h(GemmHParams p, float* workspace, size_t ws_bytes, hipStream_t s) {
     }
     ProfScope prof(FAM_GEMM, s, 2.0 * p.M * p.N * p.K);
     static bool once = false;
-    if (!once) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_h_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, H_LDS_BYTES); once = true; }
+    if (!once) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_h_kernel<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, H_LDS_BYTES);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_h_kernel<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, H_LDS_BYTES);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_h_kernel<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, H_LDS_BYTES);
+        once = true;
+    }
     const int tiles = cdiv(p.M, HM) * cdiv(p.N, HN);
-    hipLaunchKernelGGL(gemm_h_kernel, dim3(tiles * p.ksplit), dim3(256), H_LDS_BYTES, s, p);
+    if (p.a_rm)      hipLaunchKernelGGL((gemm_h_kernel<true, true>), dim3(tiles * p.ksplit), dim3(256), H_LDS_BYTES, s, p);
+    else if (p.b_rm) hipLaunchKernelGGL((gemm_h_kernel<false, true>), dim3(tiles * p.ksplit), dim3(256), H_LDS_BYTES, s, p);
+    else             hipLaunchKernelGGL((gemm_h_kernel<false, false>), dim3(tiles * p.ksplit), dim3(256), H_LDS_BYTES, s, p);
     if (int rc = check_launch("gemm_h")) return rc;
     if (p.ksplit > 1) {
         const int64_t total = (int64_t)p.M * p.N;

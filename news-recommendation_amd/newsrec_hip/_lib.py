@@ -107,6 +107,7 @@ _SIGS = {
     "nr_transpose_bf16": (c_int, [c_fp, c_int, c_i64, c_i64, c_i64, c_fp, c_i64, c_fp]),
     "nr_gemm_nt_bf16_ws_bytes": (c_sz, [c_i64, c_i64, c_i64, c_int]),
     "nr_gemm_nt_bf16": (c_int, [c_fp, c_fp, c_fp, c_i64, c_i64, c_i64, c_int, c_fp, c_fp, c_fp, c_int, c_fp, c_sz, c_fp]),
+    "nr_gemm_bf16": (c_int, [c_fp, c_int, c_i64, c_fp, c_int, c_i64, c_fp, c_i64, c_i64, c_i64, c_int, c_fp, c_fp, c_fp, c_int, c_fp, c_sz, c_fp]),
     "nr_tfm_layer_fwd_bf16": (c_int, [c_fp, c_fp, c_fp, c_fp, c_i64, c_i64, c_i64, c_i64, c_i64, C.POINTER(TfmWeights), c_f, c_u64, c_u32, c_int,
                                       C.POINTER(TfmSavedBf16), c_fp, c_fp]),
     "nr_tfm_layer_bwd_bf16_ws_bytes": (c_sz, [c_i64, c_i64]),

@@ -852,3 +852,32 @@ def test_assemble_titles_bit_exact(mode):
     assert torch.equal(keep, torch.cat([torch.ones(B * Cn, dtype=torch.int64, device="cuda"), hk.reshape(-1)]))
     with pytest.raises(ops.NewsrecError):
         ops.assemble_titles(cdd, his[:, :, :16], cm, hm, his_mask, mode)
+
+
+@pytest.mark.parametrize("layout", ["nt", "a_kc_b_rm", "both_rm"])
+@pytest.mark.parametrize("M,N,K,split", [(14080, 768, 768, 0), (768, 3072, 14080, 1), (2304, 768, 14053, 1), (200, 72, 640, 0), (136, 264, 77, 0)])
+def test_gemm_bf16_operand_layouts(layout, M, N, K, split):
+    """nr_gemm_bf16: bf16 operands as the backward finds them — k-contiguous or reduction-major (transposed LDS reads,
+    no transposed copies) — against torch's f32 product of the same bf16 values (f32 accumulate on both sides: 2e-3 of the
+    output scale covers the summation order).  Ragged edges, a reduction length that is not a multiple of 64 (both
+    operands reduction-major: rows past K read zeros), split-K."""
+    from newsrec_hip import _lib
+    L = _lib.load()
+    if layout != "both_rm" and K % 64:
+        K = (K + 63) // 64 * 64
+    g = torch.Generator(device="cuda").manual_seed(M + N + K)
+    a = torch.randn(M, K, generator=g, device="cuda").bfloat16()
+    b = torch.randn(N, K, generator=g, device="cuda").bfloat16()
+    ref = a.float() @ b.float().t()
+    a_rm, b_rm = layout == "both_rm", layout != "nt"
+    A = a.t().contiguous() if a_rm else a
+    B = b.t().contiguous() if b_rm else b
+    lda, ldb = (M if a_rm else K), (N if b_rm else K)
+    C = torch.full((M, N), float("nan"), device="cuda")
+    ws = torch.empty(L.nr_gemm_nt_bf16_ws_bytes(M, N, K, split) // 4 + 64, device="cuda")
+    st = torch.cuda.current_stream().cuda_stream
+    _lib.check(L.nr_gemm_bf16(A.data_ptr(), int(a_rm), lda, B.data_ptr(), int(b_rm), ldb, None, M, N, K, 0, C.data_ptr(), None, None,
+                              split, ws.data_ptr(), ws.numel() * 4, st), "nr_gemm_bf16")
+    torch.cuda.synchronize()
+    assert torch.isfinite(C).all()
+    assert (C - ref).abs().max().item() <= 2e-3 * ref.abs().max().item()
