@@ -297,9 +297,11 @@ typedef struct {
     float *s1, *y1, *s2;                                /* f32 [R,D]: drop(dense)+x, LN1 output (forward only), drop(dense)+y1 */
     float *stats, *row_max, *row_sum;                   /* [4,R], [N,H,S], [N,H,S] */
     uint16_t *w_h;                                      /* bf16 wqkv | wo | w1 | w2: 12 D^2 elements */
-    uint16_t *aT_h;                                     /* unused since round 3 (kept for the layout of the struct; pass NULL): the
-                                                           backward's dW products read a_h and the other row-major tensors as
-                                                           reduction-major operands (nr_gemm_bf16), no transposed copies */
+    uint16_t *wT_h;                                     /* bf16, 12 D^2 elements, may be NULL: wqkv^T [D,3D] | wo^T | w1^T [D,4D] | w2^T [4D,D],
+                                                           written by the forward in the same pass as w_h and read by the backward's
+                                                           dX products (NULL: the backward transposes the f32 weights itself).  Until
+                                                           round 2 this slot held the transposed GELU output, which nothing needs any
+                                                           more: the dW products read row-major tensors as reduction-major operands */
 } nr_tfm_saved_bf16;
 /* offs / row_map: NULL for the dense [N,S,D] layout (R = N*S), or the packed-title-token plan of nr_pack_plan / nr_pack_ids (R rows). */
 int nr_tfm_layer_fwd_bf16(const float* x, const int64_t* mask, const int32_t* offs, const int32_t* row_map, int64_t N, int64_t S, int64_t R, int64_t D, int64_t H, const nr_tfm_weights* w, float p_drop, uint64_t seed, uint32_t site_base, int mask_mode, nr_tfm_saved_bf16* saved, float* y, void* stream);

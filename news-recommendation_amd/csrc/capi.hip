@@ -869,10 +869,19 @@ int nr_tfm_layer_fwd_bf16(const float* x, const int64_t* mask, const int32_t* of
     if (N == 0 || R == 0) return NR_OK;
     hipStream_t s = S(stream);
     unsigned short* wqkv_h = sv->w_h, *wo_h = wqkv_h + 3 * DD, *w1_h = wo_h + DD, *w2_h = w1_h + 4 * DD;
-    if (int rc = cast_bf16(w->wq, wqkv_h, 3 * DD, s)) return rc;
-    if (int rc = cast_bf16(w->wo, wo_h, DD, s)) return rc;
-    if (int rc = cast_bf16(w->w1, w1_h, 4 * DD, s)) return rc;
-    if (int rc = cast_bf16(w->w2, w2_h, 4 * DD, s)) return rc;
+    if (sv->wT_h) {
+        // one pass per weight: the bf16 copy for this forward and the transposed bf16 copy the backward's dX products take
+        unsigned short* t = sv->wT_h;
+        if (int rc = transpose_bf16(w->wq, 0, D, 3 * D, D, t, 3 * D, s, wqkv_h)) return rc;                   // [3D,D] -> [D,3D]
+        if (int rc = transpose_bf16(w->wo, 0, D, D, D, t + 3 * DD, D, s, wo_h)) return rc;
+        if (int rc = transpose_bf16(w->w1, 0, D, 4 * D, D, t + 4 * DD, 4 * D, s, w1_h)) return rc;            // [4D,D] -> [D,4D]
+        if (int rc = transpose_bf16(w->w2, 0, 4 * D, D, 4 * D, t + 8 * DD, D, s, w2_h)) return rc;            // [D,4D] -> [4D,D]
+    } else {
+        if (int rc = cast_bf16(w->wq, wqkv_h, 3 * DD, s)) return rc;
+        if (int rc = cast_bf16(w->wo, wo_h, DD, s)) return rc;
+        if (int rc = cast_bf16(w->w1, w1_h, 4 * DD, s)) return rc;
+        if (int rc = cast_bf16(w->w2, w2_h, 4 * DD, s)) return rc;
+    }
     if (int rc = cast_bf16(x, sv->x_h, R * D, s)) return rc;
     float* mean1 = sv->stats ? sv->stats : nullptr;
     float* rstd1 = sv->stats ? sv->stats + R : nullptr;
@@ -882,7 +891,7 @@ int nr_tfm_layer_fwd_bf16(const float* x, const int64_t* mask, const int32_t* of
     if (int rc = mhsa_fwd_mfma_h(sv->qkv_h, mask, sv->ctx_h, sv->row_max, sv->row_sum, N, (int)Sq, (int)H, (int)(D / H), DCP(DCA(p_drop, seed, site_base, mask_mode), offs, nullptr), s)) return rc;
     if (int rc = gemm_nt(sv->ctx_h, D, wo_h, D, R, D, D, w->bo, EPI_NONE, sv->s1, nullptr, nullptr, nullptr, nullptr, s)) return rc;
     if (int rc = ln_fwd(sv->s1, x, w->ln1_g, w->ln1_b, sv->y1, sv->s1, mean1, rstd1, R, (int)D, 1e-12f, DCP(DC(p_drop, seed, site_base + 1), nullptr, row_map), s, 0, sv->y1_h)) return rc;
-    // (sv->aT_h, the transposed GELU output of round 2, is no longer written: the backward's dW2 product reads a_h as it is)
+    // (no transposed GELU output any more: the backward's dW2 product reads a_h as it is)
     if (int rc = gemm_nt(sv->y1_h, D, w1_h, D, R, 4 * D, D, w->b1, EPI_GELU, nullptr, sv->a_h, nullptr, nullptr, sv->z_h, s)) return rc;
     if (int rc = gemm_nt(sv->a_h, 4 * D, w2_h, 4 * D, R, D, 4 * D, w->b2, EPI_NONE, sv->s2, nullptr, nullptr, nullptr, nullptr, s)) return rc;
     return ln_fwd(sv->s2, sv->y1, w->ln2_g, w->ln2_b, y, sv->s2, mean2, rstd2, R, (int)D, 1e-12f, DCP(DC(p_drop, seed, site_base + 2), nullptr, row_map), s);
@@ -959,30 +968,34 @@ int nr_tfm_layer_bwd_bf16(const float* dy, const int64_t* mask, const int32_t* o
     fork(0);
     if (int rc = gemm_dw_rm(dh2_h, sv->a_h, D, 4 * D, R, g->dw2, slabs, slab_bytes, sw)) return rc;
     if (int rc = colsum(dh2, D, R, (int)D, g->db2, cpart, sw)) return rc;
-    if (int rc = transpose_bf16(w->w2, 0, 4 * D, D, 4 * D, wT, D, s)) return rc;                       // [D,4D] -> [4D,D]
-    if (int rc = gemm_nt(dh2_h, D, wT, D, R, 4 * D, D, nullptr, EPI_MUL_GELU_GRAD, nullptr, dz_h, nullptr, sv->z_h, nullptr, s)) return rc;
+    const unsigned short* w2T = sv->wT_h ? sv->wT_h + 8 * DD : wT;
+    if (!sv->wT_h) if (int rc = transpose_bf16(w->w2, 0, 4 * D, D, 4 * D, wT, D, s)) return rc;        // [D,4D] -> [4D,D]
+    if (int rc = gemm_nt(dh2_h, D, w2T, D, R, 4 * D, D, nullptr, EPI_MUL_GELU_GRAD, nullptr, dz_h, nullptr, sv->z_h, nullptr, s)) return rc;
     // FFN1: dW1 [4D,D] = dz^T y1 ; db1 ; dy1 = dz W1 + ds2
     fork(1);
     if (int rc = gemm_dw_rm(dz_h, sv->y1_h, 4 * D, D, R, g->dw1, slabs, slab_bytes, sw)) return rc;
     if (int rc = colsum_h(dz_h, 4 * D, R, (int)(4 * D), g->db1, cpart, sw)) return rc;
-    if (int rc = transpose_bf16(w->w1, 0, D, 4 * D, D, wT, 4 * D, s)) return rc;                       // [4D,D] -> [D,4D]
-    if (int rc = gemm_nt(dz_h, 4 * D, wT, 4 * D, R, D, 4 * D, nullptr, EPI_ADD_AUX, dy1, nullptr, ds2, nullptr, nullptr, s)) return rc;
+    const unsigned short* w1T = sv->wT_h ? sv->wT_h + 4 * DD : wT;
+    if (!sv->wT_h) if (int rc = transpose_bf16(w->w1, 0, D, 4 * D, D, wT, 4 * D, s)) return rc;        // [4D,D] -> [D,4D]
+    if (int rc = gemm_nt(dz_h, 4 * D, w1T, 4 * D, R, D, 4 * D, nullptr, EPI_ADD_AUX, dy1, nullptr, ds2, nullptr, nullptr, s)) return rc;
     // LN1
     if (int rc = layernorm_bwd(dy1, sv->s1, mean1, rstd1, w->ln1_g, R, (int)D, DCP(DC(p_drop, seed, site_base + 1), nullptr, row_map), ds1, p_drop > 0.f ? dh1 : nullptr, g->dln1_g, g->dln1_b, lnws, s, dh1_h)) return rc;
     // attention output projection: dWo = dh1^T ctx ; dbo ; dctx = dh1 Wo
     fork(2);
     if (int rc = gemm_dw_rm(dh1_h, sv->ctx_h, D, D, R, g->dwo, slabs, slab_bytes, sw)) return rc;
     if (int rc = colsum(dh1, D, R, (int)D, g->dbo, cpart, sw)) return rc;
-    if (int rc = transpose_bf16(w->wo, 0, D, D, D, wT, D, s)) return rc;
-    if (int rc = gemm_nt(dh1_h, D, wT, D, R, D, D, nullptr, EPI_NONE, nullptr, dctx_h, nullptr, nullptr, nullptr, s)) return rc;
+    const unsigned short* woT = sv->wT_h ? sv->wT_h + 3 * DD : wT;
+    if (!sv->wT_h) if (int rc = transpose_bf16(w->wo, 0, D, D, D, wT, D, s)) return rc;
+    if (int rc = gemm_nt(dh1_h, D, woT, D, R, D, D, nullptr, EPI_NONE, nullptr, dctx_h, nullptr, nullptr, nullptr, s)) return rc;
     // attention core
     if (int rc = mhsa_bwd_mfma_h(sv->qkv_h, mask, dctx_h, sv->row_max, sv->row_sum, dqkv_h, N, (int)Sq, (int)H, (int)(D / H), DCP(DCA(p_drop, seed, site_base, mask_mode), offs, nullptr), s)) return rc;
     // QKV projection: dWqkv [3D,D] = dqkv^T x ; dbqkv ; dx = dqkv Wqkv + ds1
     fork(3);
     if (int rc = gemm_dw_rm(dqkv_h, sv->x_h, 3 * D, D, R, g->dwq, slabs, slab_bytes, sw)) return rc;
     if (int rc = colsum_h(dqkv_h, 3 * D, R, (int)(3 * D), g->dbq, cpart, sw)) return rc;
-    if (int rc = transpose_bf16(w->wq, 0, D, 3 * D, D, wT, 3 * D, s)) return rc;                       // [3D,D] -> [D,3D]
-    if (int rc = gemm_nt(dqkv_h, 3 * D, wT, 3 * D, R, D, 3 * D, nullptr, EPI_ADD_AUX, dx, nullptr, ds1, nullptr, nullptr, s)) return rc;
+    const unsigned short* wqT = sv->wT_h ? sv->wT_h : wT;
+    if (!sv->wT_h) if (int rc = transpose_bf16(w->wq, 0, D, 3 * D, D, wT, 3 * D, s)) return rc;        // [3D,D] -> [D,3D]
+    if (int rc = gemm_nt(dqkv_h, 3 * D, wqT, 3 * D, R, D, 3 * D, nullptr, EPI_ADD_AUX, dx, nullptr, ds1, nullptr, nullptr, s)) return rc;
     return su.finish();
 }
 

@@ -44,7 +44,8 @@ int colsum(const float* in, int64_t ld, int64_t R, int N, float* out, float* par
 int colsum2(const float* a, const float* b, int64_t R, int N, float* out_a, float* out_b, float* part, hipStream_t s);
 int colsum_h(const unsigned short* in, int64_t ld, int64_t R, int N, float* out, float* part, hipStream_t s);
 int cast_bf16(const float* x, unsigned short* y, int64_t n, hipStream_t s);
-int transpose_bf16(const void* src, int src_is_bf16, int64_t ld, int64_t R, int64_t Cn, unsigned short* dst, int64_t Rp, hipStream_t s);
+int transpose_bf16(const void* src, int src_is_bf16, int64_t ld, int64_t R, int64_t Cn, unsigned short* dst, int64_t Rp, hipStream_t s,
+                   unsigned short* straight = nullptr);      // straight: also the plain bf16 copy [R, Cn] (f32 sources)
 int conv_pack(const float* w, float* wf, float* wb, int D, int E, hipStream_t s);
 int conv_unpack_grad(const float* gwf, float* gw, int D, int E, hipStream_t s);
 int add_f32(const float* a, const float* b, float* o, int64_t n, hipStream_t s);

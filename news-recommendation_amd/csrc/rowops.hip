@@ -716,7 +716,7 @@ int cast_bf16(const float* x, unsigned short* y, int64_t n, hipStream_t s) {
 // dX = dY.W and dW = dY^T.X into the NT form of gemm_h.  64 x 64 tiles through LDS, both sides in full 128-B segments.
 template <bool SRC_H>
 __global__ __launch_bounds__(256) void transpose_bf16_kernel(const void* __restrict__ src_, int64_t ld, unsigned short* __restrict__ dst,
-                                                             int64_t R, int64_t Cn, int64_t Rp) {
+                                                             int64_t R, int64_t Cn, int64_t Rp, unsigned short* __restrict__ straight) {
     __shared__ float t[64][65];
     const int64_t r0 = (int64_t)blockIdx.x * 64, c0 = (int64_t)blockIdx.y * 64;
     const int ty = threadIdx.x >> 4, tx = threadIdx.x & 15;
@@ -734,6 +734,8 @@ __global__ __launch_bounds__(256) void transpose_bf16_kernel(const void* __restr
                 } else {
                     const float4 f = *reinterpret_cast<const float4*>(static_cast<const float*>(src_) + r * ld + c);
                     v[0] = f.x; v[1] = f.y; v[2] = f.z; v[3] = f.w;
+                    // (the plain bf16 copy [R, Cn] in the same pass: the forward's weight cast and the backward's weight transpose in one read)
+                    if (straight) *reinterpret_cast<uint2*>(straight + r * Cn + c) = make_uint2(pack2_bf16(v[0], v[1]), pack2_bf16(v[2], v[3]));
                 }
             } else {
 #pragma unroll
@@ -757,13 +759,14 @@ __global__ __launch_bounds__(256) void transpose_bf16_kernel(const void* __restr
     }
 }
 // src [R, Cn] (row pitch ld; f32, or bf16 when src_is_bf16; ld % 4 == 0) -> dst [Cn, Rp], Rp % 64 == 0, Rp >= R
-int transpose_bf16(const void* src, int src_is_bf16, int64_t ld, int64_t R, int64_t Cn, unsigned short* dst, int64_t Rp, hipStream_t s) {
+int transpose_bf16(const void* src, int src_is_bf16, int64_t ld, int64_t R, int64_t Cn, unsigned short* dst, int64_t Rp, hipStream_t s, unsigned short* straight) {
     if (Cn == 0 || Rp == 0) return NR_OK;
     NR_CHECK_ARG(Rp % 64 == 0 && Rp >= R && ld % 4 == 0, "transpose_bf16: Rp=%lld must be a multiple of 64 >= R=%lld, ld %% 4 == 0", (long long)Rp, (long long)R);
+    NR_CHECK_ARG(!straight || (!src_is_bf16 && Cn % 4 == 0), "transpose_bf16: the plain copy needs an f32 source with Cn %% 4 == 0");
     ProfScope prof(FAM_MISC, s, (double)R * Cn * (src_is_bf16 ? 4 : 6));
     const dim3 grid((unsigned)(Rp / 64), (unsigned)cdiv(Cn, 64));
-    if (src_is_bf16) hipLaunchKernelGGL(transpose_bf16_kernel<true>, grid, dim3(256), 0, s, src, ld, dst, R, Cn, Rp);
-    else             hipLaunchKernelGGL(transpose_bf16_kernel<false>, grid, dim3(256), 0, s, src, ld, dst, R, Cn, Rp);
+    if (src_is_bf16) hipLaunchKernelGGL(transpose_bf16_kernel<true>, grid, dim3(256), 0, s, src, ld, dst, R, Cn, Rp, (unsigned short*)nullptr);
+    else             hipLaunchKernelGGL(transpose_bf16_kernel<false>, grid, dim3(256), 0, s, src, ld, dst, R, Cn, Rp, straight);
     return check_launch("transpose_bf16");
 }
 

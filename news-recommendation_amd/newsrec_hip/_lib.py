@@ -39,7 +39,7 @@ class TfmSaved(C.Structure):
 
 
 class TfmSavedBf16(C.Structure):
-    _fields_ = [(n, c_fp) for n in ("x_h", "qkv_h", "ctx_h", "y1_h", "z_h", "a_h", "s1", "y1", "s2", "stats", "row_max", "row_sum", "w_h", "aT_h")]
+    _fields_ = [(n, c_fp) for n in ("x_h", "qkv_h", "ctx_h", "y1_h", "z_h", "a_h", "s1", "y1", "s2", "stats", "row_max", "row_sum", "w_h", "wT_h")]
 
 
 _SIGS = {

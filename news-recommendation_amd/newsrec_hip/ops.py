@@ -579,6 +579,8 @@ class _TFMLayerBf16(torch.autograd.Function):
         f = lambda *shape: torch.empty(*shape, dtype=torch.float32, device=dev)
         bufs = dict(x_h=h(R, D), qkv_h=h(R, 3 * D), ctx_h=h(R, D), y1_h=h(R, D), z_h=h(R, 4 * D), a_h=h(R, 4 * D), s1=f(R, D), y1=f(R, D),
                     s2=f(R, D), stats=f(4, R), row_max=f(N, H, S), row_sum=f(N, H, S), w_h=h(12 * D * D))
+        if any(ctx.needs_input_grad):
+            bufs["wT_h"] = h(12 * D * D)                    # transposed bf16 weights: written with w_h, read by the backward's dX products
         y = torch.empty_like(x)
         W = TfmWeights(*[_p(t) for t in params])
         SV = TfmSavedBf16(*[_p(bufs.get(n)) for n, _ in TfmSavedBf16._fields_])
