@@ -362,10 +362,10 @@ def main():
     multi = world > 1 or os.environ.get("NR_BENCH_FORCE_DIST") == "1"
     if multi:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")       # RCCL needs dmabuf IPC on this pool (torchrun passes the env through; this covers a bare launch)
         if world == 1:
             import socket
             sk = socket.socket(); sk.bind(("127.0.0.1", 0)); os.environ.setdefault("MASTER_PORT", str(sk.getsockname()[1])); sk.close()
-            os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if rehearse:
             dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
