@@ -565,6 +565,29 @@ def main():
         "roofline": roofline, "hbm_kernels": hbm, "hbm_families_in_step": hbm_step, "kernel_ms_per_step": {k: v["ms_per_step"] for k, v in fam.items()},
     }
 
+    # ---- larger per-GPU batches, for information only (the headline stays at the reference's default -bs 32): the same step
+    # at B = 64 / 128 shows how much of the B = 32 step is fixed cost (the 1 600-row user tower, launch-bound small kernels)
+    if not extra and not multi:
+        try:
+            sweep = {}
+            for Bx in (64, 128):
+                gx = torch.Generator().manual_seed(77 + Bx)
+                bx = [{k: v.cuda() for k, v in synth_train_batch(gx, Bx, NEWS_TRAIN, ids, msk).items()} for _ in range(4)]
+
+                def stepx(i):
+                    opt.zero_grad(set_to_none=True)
+                    loss = net(bx[i % 4])
+                    model.plan_ahead(bx[(i + 1) % 4])
+                    loss.backward()
+                    opt.step()
+                    return loss
+                d, _l = timed_steps(stepx, fence, 20, 3, False, reduce_max)
+                sweep[str(Bx)] = {"impressions_per_s": round(Bx * 20 / d, 1), "ms_per_step": round(1000.0 * d / 20, 4)}
+                del bx
+            out["batch_sweep"] = sweep
+        except Exception as e:                 # noqa: BLE001 — secondary leg
+            out["batch_sweep"] = {"error": repr(e)[:200]}
+
     # ---- cached evaluation leg (BASELINE config 4 shape, per GPU): cache build + impression scoring
     if not args.no_eval:
         try:                               # a secondary leg: its failure must not take the headline line with it
