@@ -961,6 +961,63 @@ __device__ __forceinline__ f32x16 zT16(const unsigned short* Zt, const f32x16& t
     }
     return o;
 }
+// the same product with Z taken from its ROW-MAJOR tile Zr[pos][d] by transposed LDS reads (round 3): ds_read_b64_tr_b16
+// hands lane i of a 16-lane group column i of a 4-row block (lane 4q+p supplies row q, columns 4p .. 4p+3; measured lane
+// map: tools/tr_probe.hip), i.e. four consecutive positions of feature dt*32 + l31 — the two 8-byte pieces of the operand
+// above without a transposed copy of the tile.  The Xt tiles (3 of a head's 7 tiles in the backward, 1 of 3 in the
+// forward) and the 2-byte scatter stores that filled them are gone: 36.9 instead of 70.6 KB per backward workgroup at
+// head dim 64, four workgroups per CU instead of two.  (Pitch DHP + 8 keeps the b128 row reads conflict-free and leaves
+// these reads 2-way conflicted: 24 of them per head.)  EXEC must be all ones: call from wave-uniform code only.
+typedef short hs16x4 __attribute__((ext_vector_type(4)));
+typedef short hs16x8 __attribute__((ext_vector_type(8)));
+template <int DHP>
+__device__ __forceinline__ f32x16 zT16r(const unsigned short* Zr, const f32x16& tile, int dt, int lane) {
+    constexpr int PR = H16<DHP>::PR;
+    f32x16 o;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[r] = 0.f;
+    const int g = lane >> 4, q = (lane & 15) >> 2, pq = lane & 3;
+    const unsigned short* zp = Zr + (4 * (g >> 1) + q) * PR + dt * 32 + 16 * (g & 1) + 4 * pq;
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+        const hs16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) hs16x4*)(zp + (16 * kb) * PR));
+        const hs16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) hs16x4*)(zp + (16 * kb + 8) * PR));
+        const hs16x8 a8 = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(hbf16x8, a8), pack_regs16(tile, kb), o, 0, 0, 0);
+    }
+    return o;
+}
+// NSRC [Sn rows] x [nh*dh] global segments (q, k, v [, dO] of the same rows) -> row-major per-head tiles: the loads of one
+// round are all issued before the first LDS store, so the workgroup pays one HBM round trip for its operands, not NSRC
+template <int DHP, int NSRC>
+__device__ __forceinline__ void heads_in16_multi(unsigned short* const (&Rt)[NSRC], int rstride, const unsigned short* const (&g)[NSRC], const int64_t (&ld)[NSRC],
+                                                 int Sn, int dh, int nh, int tid, int nthr) {
+    constexpr int PR = H16<DHP>::PR;
+    const int nq = (nh * dh) >> 3;
+    const int pph = dh >> 3;
+    for (int idx0 = 0; idx0 < Sn * nq; idx0 += 2 * nthr) {
+        uint4 u[2][NSRC];
+        int off[2];
+        bool ok[2];
+#pragma unroll
+        for (int x = 0; x < 2; ++x) {
+            const int idx = idx0 + x * nthr + tid;
+            ok[x] = idx < Sn * nq;
+            const int r = ok[x] ? idx / nq : 0;
+            const int q = ok[x] ? idx - r * nq : 0;
+            const int hh = q / pph, d0 = (q - hh * pph) << 3;
+            off[x] = hh * rstride + r * PR + d0;
+#pragma unroll
+            for (int k = 0; k < NSRC; ++k) u[x][k] = *reinterpret_cast<const uint4*>(g[k] + (int64_t)r * ld[k] + (q << 3));
+        }
+#pragma unroll
+        for (int x = 0; x < 2; ++x)
+            if (ok[x]) {
+#pragma unroll
+                for (int k = 0; k < NSRC; ++k) *reinterpret_cast<uint4*>(Rt[k] + off[x]) = u[x][k];
+            }
+    }
+}
 // result rows = feature d (dt*32 + row(r,h)), col = position l31 -> row-major bf16 tile [pos][d]: registers 4g .. 4g+3 are
 // four consecutive features = one 8-byte store
 template <int DHP>
@@ -982,8 +1039,8 @@ __global__ __launch_bounds__(64 * NHG) void mhsa_fwd_mfma16_kernel(const unsigne
     extern __shared__ __attribute__((aligned(16))) unsigned short hsm16[];
     unsigned short* Qr = hsm16;                       // [NHG][RT]  (reused for the output tiles)
     unsigned short* Kr = Qr + NHG * RT;
-    unsigned short* Vt = Kr + NHG * RT;               // [NHG][TT]
-    float* Mk = reinterpret_cast<float*>(Vt + NHG * TT);
+    unsigned short* Vr = Kr + NHG * RT;
+    float* Mk = reinterpret_cast<float*>(Vr + NHG * RT);
     const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63, l31 = lane & 31, h = lane >> 5;
     const int groups = (H + NHG - 1) / NHG;
     const int n = blockIdx.x / groups, gidx = blockIdx.x - n * groups;
@@ -997,17 +1054,20 @@ __global__ __launch_bounds__(64 * NHG) void mhsa_fwd_mfma16_kernel(const unsigne
     // zero everything the MFMAs read (rows / positions past Sn, columns past dh), then fill
     {
         uint4* z = reinterpret_cast<uint4*>(hsm16);
-        const int n16 = (NHG * (2 * RT + TT)) >> 3;
+        const int n16 = (NHG * 3 * RT) >> 3;
         for (int i = tid; i < n16; i += NTHR) z[i] = make_uint4(0u, 0u, 0u, 0u);
     }
     if (tid < 32) Mk[tid] = tid < Sn ? (mask[(int64_t)n * S + tid] ? 0.f : dc.mask_fill) : -INFINITY;
     __syncthreads();
     const unsigned short* base = qkv + row0 * ld + hd0 * dh;
-    heads_in16<DHP>(Qr, RT, nullptr, 0, base, ld, Sn, dh, nh, tid, NTHR);
-    heads_in16<DHP>(Kr, RT, nullptr, 0, base + A, ld, Sn, dh, nh, tid, NTHR);
-    heads_in16<DHP>(nullptr, 0, Vt, TT, base + 2 * A, ld, Sn, dh, nh, tid, NTHR);
+    {
+        unsigned short* const dst[3] = {Qr, Kr, Vr};
+        const unsigned short* const src[3] = {base, base + A, base + 2 * A};
+        const int64_t lds_[3] = {ld, ld, ld};
+        heads_in16_multi<DHP, 3>(dst, RT, src, lds_, Sn, dh, nh, tid, NTHR);
+    }
     __syncthreads();
-    unsigned short* Qs = Qr + w * RT; const unsigned short* Ks = Kr + w * RT; const unsigned short* Vs = Vt + w * TT;
+    unsigned short* Qs = Qr + w * RT; const unsigned short* Ks = Kr + w * RT; const unsigned short* Vs = Vr + w * RT;
     f32x16 st;
     if (active) {
         const float sq = sqrtf((float)dh), rsq = 1.0f / sq;
@@ -1044,7 +1104,7 @@ __global__ __launch_bounds__(64 * NHG) void mhsa_fwd_mfma16_kernel(const unsigne
         }
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt) {
-            const f32x16 o = zT16(Vs, st, dt, l31, h);             // O^T[d][query]
+            const f32x16 o = zT16r<DHP>(Vs, st, dt, lane);         // O^T[d][query]
             put16<DHP>(Qs, o, dt, l31, h);                          // this wave's own Q tile: nobody else reads it
         }
     }
@@ -1064,10 +1124,7 @@ __global__ __launch_bounds__(64 * NHG) void mhsa_bwd_mfma16_kernel(const unsigne
     unsigned short* Kr = Qr + NHG * RT;
     unsigned short* Vr = Kr + NHG * RT;
     unsigned short* Gr = Vr + NHG * RT;
-    unsigned short* Qt = Gr + NHG * RT;               // transposed [NHG][TT] each
-    unsigned short* Kt = Qt + NHG * TT;
-    unsigned short* Gt = Kt + NHG * TT;
-    float* St = reinterpret_cast<float*>(Gt + NHG * TT);   // [NHG][4][32]: max, 1/sum, D, key-mask term ; then [NHG][32] keep words
+    float* St = reinterpret_cast<float*>(Gr + NHG * RT);   // [NHG][4][32]: max, 1/sum, D, key-mask term ; then [NHG][32] keep words
     const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63, l31 = lane & 31, h = lane >> 5;
     const int groups = (H + NHG - 1) / NHG;
     const int n = blockIdx.x / groups, gidx = blockIdx.x - n * groups;
@@ -1080,7 +1137,7 @@ __global__ __launch_bounds__(64 * NHG) void mhsa_bwd_mfma16_kernel(const unsigne
     if (Sn == 0) return;
     {
         uint4* z = reinterpret_cast<uint4*>(hsm16);
-        const int n16 = (NHG * (4 * RT + 3 * TT)) >> 3;
+        const int n16 = (NHG * 4 * RT) >> 3;
         for (int i = tid; i < n16; i += NTHR) z[i] = make_uint4(0u, 0u, 0u, 0u);
     }
     float* Ms = St + w * 128; float* Rl = Ms + 32; float* Dsh = Ms + 64; float* Mk = Ms + 96;
@@ -1094,13 +1151,14 @@ __global__ __launch_bounds__(64 * NHG) void mhsa_bwd_mfma16_kernel(const unsigne
     }
     __syncthreads();
     const unsigned short* base = qkv + row0 * ld + hd0 * dh;
-    heads_in16<DHP>(Qr, RT, Qt, TT, base, ld, Sn, dh, nh, tid, NTHR);
-    heads_in16<DHP>(Kr, RT, Kt, TT, base + A, ld, Sn, dh, nh, tid, NTHR);
-    heads_in16<DHP>(Vr, RT, nullptr, 0, base + 2 * A, ld, Sn, dh, nh, tid, NTHR);
-    heads_in16<DHP>(Gr, RT, Gt, TT, dctx + row0 * A + hd0 * dh, A, Sn, dh, nh, tid, NTHR);
+    {
+        unsigned short* const dst[4] = {Qr, Kr, Vr, Gr};
+        const unsigned short* const src[4] = {base, base + A, base + 2 * A, dctx + row0 * A + hd0 * dh};
+        const int64_t lds_[4] = {ld, ld, ld, (int64_t)A};
+        heads_in16_multi<DHP, 4>(dst, RT, src, lds_, Sn, dh, nh, tid, NTHR);
+    }
     __syncthreads();
     unsigned short* Qs = Qr + w * RT; unsigned short* Ks = Kr + w * RT; unsigned short* Vs = Vr + w * RT; const unsigned short* Gs = Gr + w * RT;
-    const unsigned short* Qts = Qt + w * TT; const unsigned short* Kts = Kt + w * TT; const unsigned short* Gts = Gt + w * TT;
     const int ksteps = (dh + 15) >> 4;
     const float sq = sqrtf((float)dh), rsq = 1.0f / sq;
     const float scale = dc.p > 0.f ? 1.0f / (1.0f - dc.p) : 1.0f;
@@ -1136,7 +1194,7 @@ __global__ __launch_bounds__(64 * NHG) void mhsa_bwd_mfma16_kernel(const unsigne
 #pragma unroll
             for (int r = 0; r < 16; ++r) st[r] = div_by(st[r] - pr[r] * D, sq, rsq);      // dS^T
 #pragma unroll
-            for (int dt = 0; dt < DT; ++dt) dq[dt] = zT16(Kts, st, dt, l31, h);           // dQ^T[d][query]
+            for (int dt = 0; dt < DT; ++dt) dq[dt] = zT16r<DHP>(Ks, st, dt, lane);        // dQ^T[d][query]
         }
         // Dsh / Kb were written by this wave's own lanes: LDS operations of a wave complete in order
         {
@@ -1157,8 +1215,8 @@ __global__ __launch_bounds__(64 * NHG) void mhsa_bwd_mfma16_kernel(const unsigne
             }
 #pragma unroll
             for (int dt = 0; dt < DT; ++dt) {
-                dk[dt] = zT16(Qts, ds, dt, l31, h);                // dK^T[d][key]
-                dv[dt] = zT16(Gts, pdn, dt, l31, h);               // dV^T[d][key]
+                dk[dt] = zT16r<DHP>(Qs, ds, dt, lane);             // dK^T[d][key]
+                dv[dt] = zT16r<DHP>(Gs, pdn, dt, lane);            // dV^T[d][key]
             }
         }
         // every read of this head's tiles is done (they are this wave's alone): the row-major tiles become the staging area
@@ -1195,10 +1253,10 @@ int mhsa_fwd_mfma_h(const unsigned short* qkv, const int64_t* mask, unsigned sho
         const int dhp = dh <= 32 ? 32 : 64, hpg = 2;
         const dim3 grid((unsigned)(N * ((H + hpg - 1) / hpg)));
         if (dhp == 32) {
-            const size_t lds = (size_t)hpg * (2 * H16<32>::RT + H16<32>::TT) * 2 + 128;
+            const size_t lds = (size_t)hpg * 3 * H16<32>::RT * 2 + 128;
             hipLaunchKernelGGL((mhsa_fwd_mfma16_kernel<32, 2>), grid, dim3(128), lds, s, qkv, mask, ctx, row_max, row_sum, S, H, dh, dc);
         } else {
-            const size_t lds = (size_t)hpg * (2 * H16<64>::RT + H16<64>::TT) * 2 + 128;
+            const size_t lds = (size_t)hpg * 3 * H16<64>::RT * 2 + 128;
             hipLaunchKernelGGL((mhsa_fwd_mfma16_kernel<64, 2>), grid, dim3(128), lds, s, qkv, mask, ctx, row_max, row_sum, S, H, dh, dc);
         }
         return check_launch("mhsa_fwd_mfma16");
@@ -1220,10 +1278,10 @@ int mhsa_bwd_mfma_h(const unsigned short* qkv, const int64_t* mask, const unsign
             once = true;
         }
         if (dhp == 32) {
-            const size_t lds = (size_t)hpg * (4 * H16<32>::RT + 3 * H16<32>::TT) * 2 + (size_t)hpg * 160 * 4;
+            const size_t lds = (size_t)hpg * 4 * H16<32>::RT * 2 + (size_t)hpg * 160 * 4;
             hipLaunchKernelGGL((mhsa_bwd_mfma16_kernel<32, 2>), grid, dim3(128), lds, s, qkv, mask, dctx, row_max, row_sum, dqkv, S, H, dh, dc);
         } else {
-            const size_t lds = (size_t)hpg * (4 * H16<64>::RT + 3 * H16<64>::TT) * 2 + (size_t)hpg * 160 * 4;
+            const size_t lds = (size_t)hpg * 4 * H16<64>::RT * 2 + (size_t)hpg * 160 * 4;
             hipLaunchKernelGGL((mhsa_bwd_mfma16_kernel<64, 2>), grid, dim3(128), lds, s, qkv, mask, dctx, row_max, row_sum, dqkv, S, H, dh, dc);
         }
         return check_launch("mhsa_bwd_mfma16");
