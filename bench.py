@@ -333,6 +333,7 @@ def main():
     ap.add_argument("--repeats", type=int, default=4, help="extra timed regions of --steps steps after the headline one (min/median reported)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-eval", action="store_true")
+    ap.add_argument("--no-sweep", action="store_true", help="skip the B = 64 / 128 information leg (profiling runs)")
     args = ap.parse_args()
 
     # N > 1 and not already one of N ranks: start the ranks (fresh processes; this parent never touches the GPU)
@@ -567,7 +568,7 @@ def main():
 
     # ---- larger per-GPU batches, for information only (the headline stays at the reference's default -bs 32): the same step
     # at B = 64 / 128 shows how much of the B = 32 step is fixed cost (the 1 600-row user tower, launch-bound small kernels)
-    if not extra and not multi:
+    if not extra and not multi and not args.no_sweep:
         try:
             sweep = {}
             for Bx in (64, 128):

@@ -1430,8 +1430,11 @@ __device__ __forceinline__ void store_rm_xs(uint32_t* lds, const f32x4 (&r)[2], 
 // stages an eighth of the tile (16 floats per thread).  Four waves per block ran every k-tile as 24 MFMAs + a 32-float
 // split per thread back to back, ~2 500 cycles with nothing else on the CU; halving both is what the small products
 // (125 workgroups on 256 CUs) respond to.
+// (forward form: 128 registers, so that two 8-wave workgroups share a CU and the 375 / 475-workgroup forward products of the
+// user tower run as one round, 19.0 -> 15.5 and 21.0 -> 19.1 us; the other forms need 143-155 registers and lose more to
+// spills at 128 than the second workgroup gives them: 25.5 -> 35.3 us for dX at K = 1 200)
 template <bool A_KC, bool B_KC>
-__global__ __launch_bounds__(XS_NT, 1) void gemm_x3s_kernel(const GemmParams p) {
+__global__ __launch_bounds__(XS_NT, (A_KC && B_KC) ? 4 : 1) void gemm_x3s_kernel(const GemmParams p) {
     constexpr int PL = 64 * XS_LDW;                        // dwords per plane
     __shared__ __attribute__((aligned(16))) uint32_t smem[6 * PL];   // A planes 0..2, B planes 0..2 (49 152 B); reused by the final exchange
     uint32_t* As = smem;

@@ -6,7 +6,7 @@ OUT=$PWD/gpurun_out/prof_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
 export NR_SIDE_STREAM=0
-ARGS="bench.py --steps 5 --warmup 2 --repeats 0 --no-cpu-baseline --no-eval $PROFILE_EXTRA"
+ARGS="bench.py --steps 5 --warmup 2 --repeats 0 --no-cpu-baseline --no-eval --no-sweep $PROFILE_EXTRA"
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $ARGS > $OUT/trace.log 2>&1
 python3 tools/trace_step.py $TAG > $OUT/step.txt
 tail -3 $OUT/step.txt
