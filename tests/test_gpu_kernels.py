@@ -881,3 +881,28 @@ def test_gemm_bf16_operand_layouts(layout, M, N, K, split):
     torch.cuda.synchronize()
     assert torch.isfinite(C).all()
     assert (C - ref).abs().max().item() <= 2e-3 * ref.abs().max().item()
+
+
+def test_round3_entry_points_refuse_bad_arguments():
+    """nr_gemm_bf16 / nr_assemble_titles return a status and a message instead of launching on arguments they cannot serve"""
+    from newsrec_hip import _lib, ops
+    L = _lib.load()
+    st = torch.cuda.current_stream().cuda_stream
+    a = torch.zeros(128, 128, dtype=torch.bfloat16, device="cuda")
+    c = torch.zeros(128, 128, device="cuda")
+    # A reduction-major with B k-contiguous: not built
+    assert L.nr_gemm_bf16(a.data_ptr(), 1, 128, a.data_ptr(), 0, 128, None, 128, 128, 128, 0, c.data_ptr(), None, None, 0, None, 0, st) != 0
+    assert b"not built" in L.nr_last_error()
+    # a k-contiguous operand needs K % 64 == 0
+    assert L.nr_gemm_bf16(a.data_ptr(), 0, 128, a.data_ptr(), 0, 128, None, 128, 128, 100, 0, c.data_ptr(), None, None, 0, None, 0, st) != 0
+    # a reduction-major operand needs N % 8 == 0
+    assert L.nr_gemm_bf16(a.data_ptr(), 0, 128, a.data_ptr(), 1, 128, None, 128, 100, 128, 0, c.data_ptr(), None, None, 0, None, 0, st) != 0
+    # a pitch shorter than the row it strides
+    assert L.nr_gemm_bf16(a.data_ptr(), 0, 64, a.data_ptr(), 0, 128, None, 128, 128, 128, 0, c.data_ptr(), None, None, 0, None, 0, st) != 0
+    ids = torch.zeros(2, 3, 8, dtype=torch.int64, device="cuda")
+    his = torch.zeros(2, 5, 8, dtype=torch.int64, device="cuda")
+    hm = torch.ones(2, 5, dtype=torch.int64, device="cuda")
+    with pytest.raises(ops.NewsrecError):
+        ops.assemble_titles(ids, his, ids, his, hm, 3)
+    torch.cuda.synchronize()
+    assert torch.equal(c, torch.zeros_like(c))                     # nothing was launched
