@@ -864,47 +864,19 @@ int mhsa_bwd_mfma2(const float* qkv, const int64_t* mask, const float* dctx, con
 // ---------------------------------------------------------------------------------------------------------------------
 // bf16 build (tensors bf16 in HBM, parity bar 1e-2), head dim a multiple of 8: the seven products run on
 // v_mfma_f32_32x32x16_bf16 straight from bf16 LDS tiles — 4 MFMAs for Q.K^T at dh = 64 instead of 32 on the f32 instruction.
-// Two tile layouts per operand, filled from the same 16-byte global pieces:
-//   row-major   Xr[pos][d]   (pitch DHP + 8): operand of the score-shaped products (k = d, 8 consecutive d per lane)
-//   transposed  Xt[d][pos]   (pitch 44):      A operand of the products that sum over positions
-// A product that sums over positions takes its B operand from an accumulator tile: k-slot e of MFMA kb in lane half h is
-// register 8*kb + e, i.e. position 16*kb + 8*(e>>2) + 4*h + (e&3); the A operand reads the same positions of Xt as two
-// 8-byte pieces.  Softmax, dropout and the saved statistics are the f32 code of the kernels above.
+// One tile per operand, row-major Xr[pos][d] (pitch DHP + 8), filled with 16-byte global pieces: the score-shaped products
+// (k = d) read 8 consecutive d per lane with ds_read_b128; the products that sum over positions take their A operand from
+// the same tile with transposed reads (zT16r below; until round 3 from a second, transposed copy of the tile) and their B
+// operand from an accumulator tile: k-slot e of MFMA kb in lane half h is register 8*kb + e, i.e. position
+// 16*kb + 8*(e>>2) + 4*h + (e&3).  Softmax, dropout and the saved statistics are the f32 code of the kernels above.
 typedef __bf16 hbf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 hbf16x4 __attribute__((ext_vector_type(4)));
 typedef float hf32x4 __attribute__((ext_vector_type(4)));
-constexpr int H16_PT = 44;                                  // pitch of the transposed tiles (elements)
 template <int DHP> struct H16 {
     static constexpr int PR = DHP + 8;                      // pitch of the row-major tiles
-    static constexpr int RT = 32 * PR;                      // elements of a row-major tile
-    static constexpr int TT = DHP * H16_PT;                 // elements of a transposed tile
+    static constexpr int RT = 32 * PR;                      // elements of a tile
 };
 
-// [Sn rows] x [nh*dh] bf16 global segment -> per-head row-major (Rt, may be null) and transposed (Tt, may be null) tiles;
-// head stride of each is `rstride` / `tstride` elements.  dh % 8 == 0: a 16-byte piece never straddles two heads.
-template <int DHP>
-__device__ __forceinline__ void heads_in16(unsigned short* Rt, int rstride, unsigned short* Tt, int tstride, const unsigned short* __restrict__ g,
-                                           int64_t ld, int Sn, int dh, int nh, int tid, int nthr) {
-    constexpr int PR = H16<DHP>::PR;
-    const int nq = (nh * dh) >> 3;
-    const int pph = dh >> 3;                                // pieces per head
-    for (int idx = tid; idx < Sn * nq; idx += nthr) {
-        const int r = idx / nq;
-        const int q = idx - r * nq;
-        const int hh = q / pph, d0 = (q - hh * pph) << 3;
-        const uint4 u = *reinterpret_cast<const uint4*>(g + (int64_t)r * ld + (q << 3));
-        if (Rt) *reinterpret_cast<uint4*>(Rt + hh * rstride + r * PR + d0) = u;
-        if (Tt) {
-            unsigned short* t = Tt + hh * tstride + d0 * H16_PT + r;
-            const uint32_t w[4] = {u.x, u.y, u.z, u.w};
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                t[(2 * k) * H16_PT] = (unsigned short)(w[k] & 0xffffu);
-                t[(2 * k + 1) * H16_PT] = (unsigned short)(w[k] >> 16);
-            }
-        }
-    }
-}
 // per-head row-major tiles [pos][d] -> [Sn rows] x [nh*dh] bf16 global segment
 template <int DHP>
 __device__ __forceinline__ void heads_out16(unsigned short* __restrict__ g, int64_t ld, const unsigned short* Rt, int rstride, int Sn, int dh,
@@ -945,29 +917,15 @@ __device__ __forceinline__ hbf16x8 pack_regs16(const f32x16& t, int kb) {
     for (int e = 0; e < 8; ++e) o[e] = (__bf16)t[8 * kb + e];
     return o;
 }
-// out[r] = sum over positions k of Zt[dt*32 + row(r,h)][k] * tile[k][l31]  (tile = an accumulator tile whose ROW index is k)
-__device__ __forceinline__ f32x16 zT16(const unsigned short* Zt, const f32x16& tile, int dt, int l31, int h) {
-    f32x16 o;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) o[r] = 0.f;
-    const unsigned short* zp = Zt + (dt * 32 + l31) * H16_PT + 4 * h;
-#pragma unroll
-    for (int kb = 0; kb < 2; ++kb) {
-        const uint2 lo = *reinterpret_cast<const uint2*>(zp + 16 * kb);
-        const uint2 hi = *reinterpret_cast<const uint2*>(zp + 16 * kb + 8);
-        const uint4 a4 = make_uint4(lo.x, lo.y, hi.x, hi.y);
-        const hbf16x8 fa = __builtin_bit_cast(hbf16x8, a4);
-        o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, pack_regs16(tile, kb), o, 0, 0, 0);
-    }
-    return o;
-}
-// the same product with Z taken from its ROW-MAJOR tile Zr[pos][d] by transposed LDS reads (round 3): ds_read_b64_tr_b16
+// out[r] = sum over positions k of Z[k][dt*32 + row(r,h)] * tile[k][l31]  (tile = an accumulator tile whose ROW index is k),
+// Z taken from its ROW-MAJOR tile Zr[pos][d] by transposed LDS reads (round 3): ds_read_b64_tr_b16
 // hands lane i of a 16-lane group column i of a 4-row block (lane 4q+p supplies row q, columns 4p .. 4p+3; measured lane
 // map: tools/tr_probe.hip), i.e. four consecutive positions of feature dt*32 + l31 — the two 8-byte pieces of the operand
 // above without a transposed copy of the tile.  The Xt tiles (3 of a head's 7 tiles in the backward, 1 of 3 in the
 // forward) and the 2-byte scatter stores that filled them are gone: 36.9 instead of 70.6 KB per backward workgroup at
 // head dim 64, four workgroups per CU instead of two.  (Pitch DHP + 8 keeps the b128 row reads conflict-free and leaves
 // these reads 2-way conflicted: 24 of them per head.)  EXEC must be all ones: call from wave-uniform code only.
+// Until round 3 the operand came as two 8-byte pieces of a transposed copy Xt[d][pos] of the tile.
 typedef short hs16x4 __attribute__((ext_vector_type(4)));
 typedef short hs16x8 __attribute__((ext_vector_type(8)));
 template <int DHP>
@@ -1034,7 +992,7 @@ template <int DHP, int NHG>
 __global__ __launch_bounds__(64 * NHG) void mhsa_fwd_mfma16_kernel(const unsigned short* __restrict__ qkv, const int64_t* __restrict__ mask,
                                                                unsigned short* __restrict__ ctx, float* __restrict__ row_max,
                                                                float* __restrict__ row_sum, int S, int H, int dh, DropoutCfg dc) {
-    constexpr int RT = H16<DHP>::RT, TT = H16<DHP>::TT, NTHR = 64 * NHG;
+    constexpr int RT = H16<DHP>::RT, NTHR = 64 * NHG;
     constexpr int DT = DHP / 32;
     extern __shared__ __attribute__((aligned(16))) unsigned short hsm16[];
     unsigned short* Qr = hsm16;                       // [NHG][RT]  (reused for the output tiles)
@@ -1117,7 +1075,7 @@ __global__ __launch_bounds__(64 * NHG) void mhsa_bwd_mfma16_kernel(const unsigne
                                                                const unsigned short* __restrict__ dctx, const float* __restrict__ row_max,
                                                                const float* __restrict__ row_sum, unsigned short* __restrict__ dqkv,
                                                                int S, int H, int dh, DropoutCfg dc) {
-    constexpr int RT = H16<DHP>::RT, TT = H16<DHP>::TT, NTHR = 64 * NHG;
+    constexpr int RT = H16<DHP>::RT, NTHR = 64 * NHG;
     constexpr int DT = DHP / 32;
     extern __shared__ __attribute__((aligned(16))) unsigned short hsm16[];
     unsigned short* Qr = hsm16;                       // row-major [NHG][RT] each
