@@ -482,7 +482,7 @@ def main():
                              "pieces_alone = each collective by itself"}
     fam = {}
     for name, idx in (("gemm", 0), ("gather", 1), ("attention", 2), ("layernorm", 3), ("pool", 4), ("score", 5), ("misc", 6), ("scatter_add", 7),
-                      ("gemm_split", 8)):
+                      ("gemm_split", 8), ("hbm_small", 9)):
         ms, n, work = ops.prof_read(idx)
         fam[name] = dict(ms_per_step=round(ms / args.steps, 4), launches_per_step=n / args.steps, work_per_step=work / args.steps)
     ops.prof_enable(False)
@@ -542,6 +542,10 @@ def main():
         if f["ms_per_step"] > 0:
             gbs = f["work_per_step"] / (f["ms_per_step"] * 1e-3) / 1e9
             hbm_step[name] = {"GB/s": round(gbs, 1), "frac_of_8TBs": round(gbs / PEAK_HBM_GBS, 4), "ms_per_step": f["ms_per_step"]}
+    f = fam["hbm_small"]
+    hbm_step["small_launches"] = {"ms_per_step": f["ms_per_step"], "launches_per_step": f["launches_per_step"], "MB_per_step": round(f["work_per_step"] / 1e6, 2),
+                                  "note": "launches of the gather / layernorm / pool / score families that move under 16 MB (the 32-sequence user-tower calls, "
+                                          "the 32-row scoring): launch-bound, booked apart from the families above"}
     try:
         with torch.no_grad():
             hbm = hbm_kernel_leg(model, B, batches[0]) if not extra else {}

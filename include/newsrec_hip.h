@@ -44,7 +44,8 @@ const char* nr_last_error(void);
  * nr_prof_read synchronises those events, returns the family's summed device time (ms), launch
  * count and summed algorithmic work (flops for family 0, bytes otherwise) and clears them. */
 enum { NR_FAM_GEMM = 0, NR_FAM_GATHER = 1, NR_FAM_ATTN = 2, NR_FAM_LN = 3, NR_FAM_POOL = 4, NR_FAM_SCORE = 5, NR_FAM_MISC = 6, NR_FAM_SCATTER = 7,
-       NR_FAM_GEMM_SPLIT = 8 /* the split-operand GEMM launches of mode 2; NR_FAM_GEMM then holds the rest */, NR_FAM_COUNT = 9 };
+       NR_FAM_GEMM_SPLIT = 8 /* the split-operand GEMM launches of mode 2; NR_FAM_GEMM then holds the rest */,
+       NR_FAM_HBM_SMALL = 9 /* launches of families 1, 3, 4, 5 that move under 16 MB (launch-bound: booked apart) */, NR_FAM_COUNT = 10 };
 int nr_prof_enable(int on);
 int nr_prof_read(int family, double* ms, int64_t* launches, double* work);
 

@@ -33,13 +33,18 @@ void set_error(const char* fmt, ...);
 int check_launch(const char* what);
 
 // optional per-family kernel timing (bench.py roofline leg); see prof.hip
-enum Family { FAM_GEMM = 0, FAM_GATHER, FAM_ATTN, FAM_LN, FAM_POOL, FAM_SCORE, FAM_MISC, FAM_SCATTER, FAM_GEMM_SPLIT, FAM_COUNT };
+enum Family { FAM_GEMM = 0, FAM_GATHER, FAM_ATTN, FAM_LN, FAM_POOL, FAM_SCORE, FAM_MISC, FAM_SCATTER, FAM_GEMM_SPLIT, FAM_HBM_SMALL, FAM_COUNT };
 void prof_begin(int family, hipStream_t s, double work);
 void prof_end(int family, hipStream_t s);
 
 struct ProfScope {
     int fam; hipStream_t s;
-    ProfScope(int f, hipStream_t st, double work) : fam(f), s(st) { prof_begin(f, st, work); }
+    // launches of the HBM-bound families that move under 16 MB (the 32-sequence user-tower calls, the 32-row scoring) are
+    // launch-bound, not bandwidth-bound: they are booked apart so that a family's GB/s is that of its real launches
+    ProfScope(int f, hipStream_t st, double work) : fam(f), s(st) {
+        if ((f == FAM_LN || f == FAM_POOL || f == FAM_GATHER || f == FAM_SCORE) && work < 16e6) fam = FAM_HBM_SMALL;
+        prof_begin(fam, st, work);
+    }
     ~ProfScope() { prof_end(fam, s); }
 };
 
