@@ -74,12 +74,6 @@ int nr_set_gemm_compute(int mode);
  * kernels one at a time; returns the previous setting.  NR_SIDE_STREAM=0 in the environment sets the initial value. */
 int nr_set_side_stream(int on);
 int nr_get_gemm_compute(void);
-/* (no counterpart in the reference) process-wide kernel tuning switches, for A/B measurements inside one process
- * (tools/gemm_ab.py, tools/layer_ab.py).  key 0: raise the wave priority around the MFMA block of gemm_x3_kernel's k-loop
- * (measured: +0.7 %, off).  key 1: nr_tfm_layer_fwd_f32 saves gelu'(z) instead of z and the backward multiplies by it
- * (measured: forward +38 us, backward -23 us at 19 936 rows: off; flip it only between whole steps).
- * Results never depend on them.  Returns the previous value. */
-int nr_set_tuning(int key, int value);
 
 /* ---- (i) token-embedding gather — nn.Embedding lookup, models/modules/encoder.py:52,135 ------
  * out[r,:] = table[ids[r],:] (bit-exact).  *oob_flag (device int, may be NULL) is set to 1 if any

@@ -92,11 +92,10 @@ static void maybe_split(GemmParams& p, float* ws, size_t ws_bytes) {
     if (ks > 1 && gemm_workspace_bytes(p.M, p.N, ks) <= ws_bytes) p.ksplit = ks;
 }
 static int linear_fwd(const float* x, int64_t ldx, const float* w, const float* b, int64_t R, int64_t K, int64_t N, int epi,
-                      float* y, float* z, hipStream_t s, float* ws = nullptr, size_t ws_bytes = 0, bool z_is_gelu_grad = false) {
+                      float* y, float* z, hipStream_t s, float* ws = nullptr, size_t ws_bytes = 0) {
     GemmParams p;
     p.A = x; p.lda = ldx; p.B = w; p.ldb = K; p.C = y; p.ldc = N;
     p.M = (int)R; p.N = (int)N; p.K = (int)K; p.bias = b; p.epi = epi; p.out2 = z; p.ldout2 = N;
-    p.gelu_save_grad = z_is_gelu_grad ? 1 : 0;
     maybe_split(p, ws, ws_bytes);
     return gemm_f32(p, true, true, ws, ws_bytes, s);
 }
@@ -158,12 +157,6 @@ int nr_set_side_stream(int on) {
     return g_side_on.exchange(on ? 1 : 0);
 }
 int nr_get_gemm_compute(void) { return nr::get_gemm_compute(); }
-int nr_set_tuning(int key, int value) {
-    NR_CHECK_ARG(key >= 0 && key < TUNE_COUNT, "nr_set_tuning: key %d out of range", key);
-    const int old = nr::get_tuning(key);
-    nr::set_tuning(key, value);
-    return old;
-}
 const char* nr_last_error(void) { return g_err; }
 
 int nr_prof_enable(int on) {
@@ -711,9 +704,7 @@ static int tfm_layer_fwd(const float* x, const int64_t* mask, int64_t N, int64_t
     if (int rc = linear_fwd(sv->ctx, D, w->wo, w->bo, R, D, D, EPI_NONE, sv->s1, nullptr, s)) return rc;
     if (int rc = ln_fwd(sv->s1, x, w->ln1_g, w->ln1_b, sv->y1, sv->s1, mean1, rstd1, R, (int)D, 1e-12f,
                         DCP(DC(p_drop, seed, site_base + 1), nullptr, row_map), s)) return rc;
-    // (experiment, nr_set_tuning(1, 1): sv->z receives gelu'(pre-activation) and the backward multiplies by it; set it for
-    // a whole step or not at all — forward and backward must agree)
-    if (int rc = linear_fwd(sv->y1, D, w->w1, w->b1, R, D, 4 * D, EPI_GELU, sv->a, sv->z, s, nullptr, 0, get_tuning(TUNE_GELU_SAVE_GRAD) != 0)) return rc;
+    if (int rc = linear_fwd(sv->y1, D, w->w1, w->b1, R, D, 4 * D, EPI_GELU, sv->a, sv->z, s)) return rc;
     if (int rc = linear_fwd(sv->a, 4 * D, w->w2, w->b2, R, 4 * D, D, EPI_NONE, sv->s2, nullptr, s)) return rc;
     return ln_fwd(sv->s2, sv->y1, w->ln2_g, w->ln2_b, y, sv->s2, mean2, rstd2, R, (int)D, 1e-12f,
                   DCP(DC(p_drop, seed, site_base + 2), nullptr, row_map), s);
@@ -781,7 +772,7 @@ static int tfm_layer_bwd(const float* dy, const float* x, const int64_t* mask, i
     fork(0);
     if (int rc = layernorm_bwd_params(R, (int)D, g->dln2_g, g->dln2_b, lnws, sw)) return rc;
     if (int rc = linear_bwd_weight(dh2, D, sv->a, 4 * D, R, D, 4 * D, g->dw2, g->db2, wws, wws_bytes, 0, 0, sw)) return rc;
-    if (int rc = linear_bwd_input(dh2, D, w->w2, R, D, 4 * D, get_tuning(TUNE_GELU_SAVE_GRAD) ? EPI_MUL_AUX : EPI_MUL_GELU_GRAD, sv->z, nullptr, dz, s)) return rc;
+    if (int rc = linear_bwd_input(dh2, D, w->w2, R, D, 4 * D, EPI_MUL_GELU_GRAD, sv->z, nullptr, dz, s)) return rc;
     // FFN1: dW1 = dz^T y1 ; dy1 = dz W1 + ds2 (residual)
     fork(1);
     if (int rc = linear_bwd_weight(dz, 4 * D, sv->y1, D, R, 4 * D, D, g->dw1, g->db1, wws, wws_bytes, 0, 0, sw)) return rc;
@@ -848,15 +839,6 @@ static int gemm_nt(const unsigned short* A, int64_t lda, const unsigned short* B
     p.aux = aux; p.ldaux = N; p.auxh = auxh; p.ldauxh = N; p.out2h = out2h; p.ldout2h = N;
     return gemm_h(p, nullptr, 0, s);
 }
-// dW [N,K] = dY^T X from the transposed copies dyT [N,Rp], xT [K,Rp] (split over the reduction, slabs in ws)
-static int gemm_dw(const unsigned short* dyT, const unsigned short* xT, int64_t N, int64_t K, int64_t Rp, float* dw, float* ws, size_t ws_bytes, hipStream_t s) {
-    GemmHParams p;
-    p.A = dyT; p.lda = Rp; p.B = xT; p.ldb = Rp; p.M = (int)N; p.N = (int)K; p.K = (int)Rp;
-    p.C = dw; p.ldc = K;
-    p.ksplit = choose_ksplit_h(p.M, p.N, p.K);
-    return gemm_h(p, ws, ws_bytes, s);
-}
-
 int nr_tfm_layer_fwd_bf16(const float* x, const int64_t* mask, const int32_t* offs, const int32_t* row_map, int64_t N, int64_t Sq, int64_t R, int64_t D, int64_t H, const nr_tfm_weights* w, float p_drop, uint64_t seed, uint32_t site_base, int mask_mode, nr_tfm_saved_bf16* sv, float* y, void* stream) {
     NR_CHECK_ARG(N >= 0 && Sq > 0 && D > 0 && H > 0 && R >= 0 && R <= N * Sq, "tfm_layer_fwd_bf16: bad sizes");
     NR_CHECK_ARG((offs == nullptr) == (row_map == nullptr) && (offs || R == N * Sq), "tfm_layer_fwd_bf16: packed rows need offs and row_map; dense rows R = N*S");
@@ -934,7 +916,6 @@ int nr_tfm_layer_bwd_bf16(const float* dy, const int64_t* mask, const int32_t* o
     NR_CHECK_ARG(contiguous3(g->dwq, g->dwk, g->dwv, DD) && contiguous3(g->dbq, g->dbk, g->dbv, (size_t)D), "tfm_layer_bwd_bf16: q|k|v gradients must be contiguous");
     if (!ws || ws_bytes < nr_tfm_layer_bwd_bf16_ws_bytes(R, D)) { set_error("tfm_layer_bwd_bf16: workspace too small"); return NR_ERR_WORKSPACE; }
     hipStream_t s = S(stream);
-    const int64_t Rp = (R + 63) / 64 * 64;
     char* cur = (char*)ws;
     float* ds2 = bump(cur, (size_t)R * D);
     float* dh2 = p_drop > 0.f ? bump(cur, (size_t)R * D) : ds2;

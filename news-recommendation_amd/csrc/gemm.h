@@ -14,7 +14,6 @@ enum Epilogue {
     EPI_MUL_GELU_GRAD = 5,     // y = (acc + bias) * gelu'(aux)
     EPI_ADD_AUX_RELUMASK = 6,  // y = (acc + bias + aux) * (aux2 > 0)
     EPI_RELUMASK = 7,          // y = (acc + bias) * (aux2 > 0)
-    EPI_MUL_AUX = 8,           // y = (acc + bias) * aux
 };
 
 struct GemmParams {
@@ -37,14 +36,7 @@ struct GemmParams {
     // tiles already in LDS; csum_part [ksplit, M] is scratch for the split-K case
     float* csum = nullptr;
     float* csum_part = nullptr;
-    int gelu_save_grad = 0;    // EPI_GELU only: out2 receives gelu'(z) instead of z (the factor the backward multiplies by:
-                               // the erf is shared with the forward's own gelu(z), so the backward's epilogue is a plain product)
-    int tune = 0;              // bit 0: raise the wave priority around the MFMA block of the k-loop (set by gemm_f32 from g_tune)
 };
-// process-wide tuning switches (nr_set_tuning; A/B measurements in one process)
-enum { TUNE_X3_PRIO = 0, TUNE_GELU_SAVE_GRAD = 1 /* 1: the layer forward saves gelu'(z) instead of z (measured: forward +38 us, backward -23 us at the headline shape: off) */, TUNE_COUNT = 8 };
-void set_tuning(int key, int value);
-int get_tuning(int key);
 
 // bf16-in-HBM "NT" GEMM (gemm_h.hip): C[m,n] = epi(sum_k A[m,k] B[n,k] + bias[n]); A [M,K], B [N,K] bf16 k-contiguous
 // (raw 16-bit storage), f32 accumulate.  Outputs: C (f32, may be NULL) and / or Ch (bf16, may be NULL).

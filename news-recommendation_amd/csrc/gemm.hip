@@ -171,28 +171,26 @@ __device__ __forceinline__ float epi_math(float v, float a, float a2) {
     if (EPI == EPI_MUL_GELU_GRAD) return v * gelu_grad_f(a);
     if (EPI == EPI_ADD_AUX_RELUMASK) return a2 > 0.f ? v + a : 0.f;
     if (EPI == EPI_RELUMASK) return a2 > 0.f ? v : 0.f;
-    if (EPI == EPI_MUL_AUX) return v * a;
     return v;
 }
 template <int EPI> struct EpiTraits {
-    static constexpr bool AUX = EPI == EPI_ADD_AUX || EPI == EPI_MUL_GELU_GRAD || EPI == EPI_ADD_AUX_RELUMASK || EPI == EPI_MUL_AUX;
+    static constexpr bool AUX = EPI == EPI_ADD_AUX || EPI == EPI_MUL_GELU_GRAD || EPI == EPI_ADD_AUX_RELUMASK;
     static constexpr bool AUX2 = EPI == EPI_ADD_AUX_RELUMASK || EPI == EPI_RELUMASK;
 };
 
 __device__ __forceinline__ float epilogue(float v, int epi, int m, int n, const GemmParams& p) {
-    const float a = (epi == EPI_ADD_AUX || epi == EPI_MUL_GELU_GRAD || epi == EPI_ADD_AUX_RELUMASK || epi == EPI_MUL_AUX) ? p.aux[(int64_t)m * p.ldaux + n] : 0.f;
+    const float a = (epi == EPI_ADD_AUX || epi == EPI_MUL_GELU_GRAD || epi == EPI_ADD_AUX_RELUMASK) ? p.aux[(int64_t)m * p.ldaux + n] : 0.f;
     const float a2 = (epi == EPI_ADD_AUX_RELUMASK || epi == EPI_RELUMASK) ? p.aux2[(int64_t)m * p.ldaux2 + n] : 0.f;
     switch (epi) {
         case EPI_RELU: return epi_math<EPI_RELU>(v, a, a2);
         case EPI_GELU:
-            if (p.out2) p.out2[(int64_t)m * p.ldout2 + n] = p.gelu_save_grad ? gelu_grad_f(v) : v;
+            if (p.out2) p.out2[(int64_t)m * p.ldout2 + n] = v;
             return epi_math<EPI_GELU>(v, a, a2);
         case EPI_TANH: return epi_math<EPI_TANH>(v, a, a2);
         case EPI_ADD_AUX: return epi_math<EPI_ADD_AUX>(v, a, a2);
         case EPI_MUL_GELU_GRAD: return epi_math<EPI_MUL_GELU_GRAD>(v, a, a2);
         case EPI_ADD_AUX_RELUMASK: return epi_math<EPI_ADD_AUX_RELUMASK>(v, a, a2);
         case EPI_RELUMASK: return epi_math<EPI_RELUMASK>(v, a, a2);
-        case EPI_MUL_AUX: return epi_math<EPI_MUL_AUX>(v, a, a2);
     }
     return v;
 }
@@ -250,7 +248,7 @@ __device__ __forceinline__ void store_block(const f32x16 (&acc)[WM][NJ], float* 
                 const int ro = (r & 3) + 8 * (r >> 2);
                 if (CHECK && ml + ro >= p.M) continue;
                 const float v = acc[i][j][r] + bv;
-                if (EPI == EPI_GELU && ob) at_off(ob + ro * ldout2, vo2) = p.gelu_save_grad ? gelu_grad_f(v) : v;
+                if (EPI == EPI_GELU && ob) at_off(ob + ro * ldout2, vo2) = v;
                 at_off(cb + ro * ldc, vc) = epi_math<EPI>(v, EpiTraits<EPI>::AUX ? a[r] : 0.f, EpiTraits<EPI>::AUX2 ? a2[r] : 0.f);
             }
         }
@@ -263,7 +261,7 @@ template <int WM, int NJ, bool CHECK>
 __device__ __forceinline__ void store_block_rt(const f32x16 (&acc)[WM][NJ], float* C, int mw, int nw, int l31, int h,
                                             bool use_bias, int epi, const GemmParams& p) {
     const int64_t ldc = p.ldc, ldaux = p.ldaux, ldaux2 = p.ldaux2, ldout2 = p.ldout2;
-    const bool has_aux = epi == EPI_ADD_AUX || epi == EPI_MUL_GELU_GRAD || epi == EPI_ADD_AUX_RELUMASK || epi == EPI_MUL_AUX;
+    const bool has_aux = epi == EPI_ADD_AUX || epi == EPI_MUL_GELU_GRAD || epi == EPI_ADD_AUX_RELUMASK;
     const bool has_aux2 = epi == EPI_ADD_AUX_RELUMASK || epi == EPI_RELUMASK;
     const bool has_out2 = epi == EPI_GELU && p.out2 != nullptr;
     const uint32_t vc = (uint32_t)(4 * h * (int)ldc + l31) * 4u;
@@ -305,18 +303,10 @@ __device__ __forceinline__ void store_block_rt(const f32x16 (&acc)[WM][NJ], floa
             for (int r = 0; r < 16; ++r) v[r] = acc[i][j][r] + bv;
             if (has_out2) {
                 float* ob = p.out2 + mb * ldout2 + nb;
-                if (p.gelu_save_grad) {          // gelu'(z): shares its erf with the gelu(z) of the switch below
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int ro = (r & 3) + 8 * (r >> 2);
-                        if (!CHECK || ml + ro < p.M) at_off(ob + ro * ldout2, vo2) = gelu_grad_f(v[r]);
-                    }
-                } else {
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int ro = (r & 3) + 8 * (r >> 2);
-                        if (!CHECK || ml + ro < p.M) at_off(ob + ro * ldout2, vo2) = v[r];
-                    }
+                for (int r = 0; r < 16; ++r) {
+                    const int ro = (r & 3) + 8 * (r >> 2);
+                    if (!CHECK || ml + ro < p.M) at_off(ob + ro * ldout2, vo2) = v[r];
                 }
             }
             switch (epi) {
@@ -347,10 +337,6 @@ __device__ __forceinline__ void store_block_rt(const f32x16 (&acc)[WM][NJ], floa
                 case EPI_RELUMASK:
 #pragma unroll
                     for (int r = 0; r < 16; ++r) v[r] = epi_math<EPI_RELUMASK>(v[r], a[r], a2[r]);
-                    break;
-                case EPI_MUL_AUX:
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) v[r] = epi_math<EPI_MUL_AUX>(v[r], a[r], a2[r]);
                     break;
                 default: break;
             }
@@ -581,7 +567,6 @@ __global__ __launch_bounds__(256, (WM * NJ <= 2) ? 4 : 2) void gemm_f32_kernel(c
             case EPI_MUL_GELU_GRAD: NR_STORE(EPI_MUL_GELU_GRAD); break;
             case EPI_ADD_AUX_RELUMASK: NR_STORE(EPI_ADD_AUX_RELUMASK); break;
             case EPI_RELUMASK: NR_STORE(EPI_RELUMASK); break;
-            case EPI_MUL_AUX: NR_STORE(EPI_MUL_AUX); break;
         }
     }
 #undef NR_STORE
@@ -1203,13 +1188,8 @@ __global__ __launch_bounds__(256, NR_X3_WGS) void gemm_x3_kernel(const GemmParam
 #else
         fload(f1, 1);
 #endif
-        // the partner workgroup's wave on this SIMD is in its staging phase (a dense stream of independent VALU) while
-        // this one multiplies: vector issue is arbitrated by priority, then AGE, so without a priority an older
-        // staging wave starves a younger wave's MFMAs and the two phases add instead of overlapping
-        if (p.tune & 1) __builtin_amdgcn_s_setprio(1);
         fmma(f0);
         fmma(f1);
-        if (p.tune & 1) __builtin_amdgcn_s_setprio(0);
 #endif
         if (kt - kt_begin < 6) X3_STAMP(3 + 4 * (kt - kt_begin));
         __syncthreads();                                  // everyone is done reading the single stage
@@ -1640,9 +1620,6 @@ static bool x3s_eligible(int M, int N, int K, int ksplit) {
 }
 
 static std::atomic<int> g_gemm_compute{2};       // default: fp32 results from split operands on the bf16 matrix pipe
-static std::atomic<int> g_tune[TUNE_COUNT] = {};
-void set_tuning(int key, int value) { if (key >= 0 && key < TUNE_COUNT) g_tune[key].store(value); }
-int get_tuning(int key) { return key >= 0 && key < TUNE_COUNT ? g_tune[key].load() : 0; }
 void set_gemm_compute(int mode) { g_gemm_compute.store(mode); }
 int get_gemm_compute() { return g_gemm_compute.load(); }
 
@@ -1820,7 +1797,6 @@ int gemm_f32(GemmParams p, bool a_kc, bool b_kc, float* workspace, size_t ws_byt
                     !(p.ksplit > 1 && x3_prefers_small(p.M, p.N));
     const bool x3s = !x3 && fast && g_gemm_compute.load() == 2 && (a_kc || !b_kc) && x3s_eligible(p.M, p.N, p.K, p.ksplit);
     ProfScope prof(x3 ? FAM_GEMM_SPLIT : FAM_GEMM, s, 2.0 * p.M * p.N * p.K);
-    p.tune = g_tune[TUNE_X3_PRIO].load() ? 1 : 0;
     if (!fast) {
         p.ksplit = 1;
         const int64_t total = (int64_t)p.M * p.N;

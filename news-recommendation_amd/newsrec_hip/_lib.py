@@ -53,7 +53,6 @@ _SIGS = {
     "nr_assemble_titles": (c_int, [c_fp, c_fp, c_fp, c_fp, c_fp, c_int, c_i64, c_i64, c_i64, c_i64, c_fp, c_fp, c_fp, c_fp]),
     "nr_query_pool_packed_bwd_split_f32": (c_int, [c_fp, c_fp, c_fp, c_i64, c_fp, c_fp, c_fp, c_fp, c_i64, c_i64, c_i64, c_i64, c_int,
                                                    c_fp, c_fp, c_fp, c_fp, c_sz, c_fp]),
-    "nr_set_tuning": (c_int, [c_int, c_int]),
     "nr_prof_read": (c_int, [c_int, C.POINTER(C.c_double), C.POINTER(c_i64), C.POINTER(C.c_double)]),
     "nr_gather_rows_f32": (c_int, [c_fp, c_i64, c_i64, c_fp, c_i64, c_fp, c_fp, c_fp]),
     "nr_scatter_add_rows_f32": (c_int, [c_fp, c_fp, c_i64, c_i64, c_i64, c_i64, c_fp, c_fp]),
