@@ -1,10 +1,13 @@
 """diagnostic (library built with -DNR_X3_EXP=4): where a workgroup of gemm_x3_kernel spends its cycles
-usage: python tools/x3_stamps.py R K N [BK]"""
+usage: [X3_LIB=libnewsrec_hip_exp4.so] python tools/x3_stamps.py R K N [BK]"""
 import ctypes, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "news-recommendation_amd"))
 import numpy as np, torch
-from newsrec_hip import ops, _lib
+from newsrec_hip import _lib
+if os.environ.get("X3_LIB"):
+    _lib.LIB_PATH = os.path.join(os.path.dirname(_lib.LIB_PATH), os.environ["X3_LIB"])
+from newsrec_hip import ops
 R, K, N = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])
 x = torch.randn(R, K, device="cuda"); w = torch.randn(N, K, device="cuda") / K ** 0.5; b = torch.randn(N, device="cuda")
 for _ in range(5):
