@@ -217,6 +217,29 @@ def cpu_baseline(B, steps=16):
                       "eval-mode dropout"}
 
 
+_REPORT_FD = None
+
+
+def quiet_stdout():
+    """From here on everything written to fd 1 — Python prints and C-level ones (RCCL's version banner and gloo's
+    connection lines go to stdout) — lands on stderr; the original stdout is kept for report(), so that this command's
+    stdout is the ONE JSON line and nothing else."""
+    global _REPORT_FD
+    if _REPORT_FD is None:
+        sys.stdout.flush()
+        _REPORT_FD = os.dup(1)
+        os.dup2(2, 1)
+
+
+def report(obj):
+    line = (json.dumps(obj) + "\n").encode()
+    if _REPORT_FD is None:
+        sys.stdout.write(line.decode()); sys.stdout.flush()
+        return
+    sys.stdout.flush()
+    os.write(_REPORT_FD, line)
+
+
 def launch_ranks(n, argv, extra_env=None, timeout=None):
     """start `n` fresh processes of this file, one per GPU, with the torch.distributed environment (RANK, LOCAL_RANK,
     WORLD_SIZE, MASTER_ADDR=127.0.0.1, MASTER_PORT = a free port) and wait for them.  The caller must not have touched
@@ -311,9 +334,9 @@ def stub_worker(args):
         dist.all_gather(both, flat)
         same = all(torch.equal(both[0], b) for b in both)
     if rank == 0:
-        print(json.dumps({"metric": "stub", "stub": True, "value": world * args.batch_size * args.steps / dt, "n_gpus": world,
-                          "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1000.0 * dt / args.steps,
-                          "replicas_identical": same, "scaling": "weak"}))
+        report({"metric": "stub", "stub": True, "value": world * args.batch_size * args.steps / dt, "n_gpus": world,
+                "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1000.0 * dt / args.steps,
+                "replicas_identical": same, "scaling": "weak"})
     if world > 1:
         dist.destroy_process_group()
 
@@ -339,6 +362,7 @@ def main():
     # N > 1 and not already one of N ranks: start the ranks (fresh processes; this parent never touches the GPU)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         raise SystemExit(launch_ranks(args.gpus, sys.argv[1:]))
+    quiet_stdout()
     if os.environ.get("NR_BENCH_STUB") == "1":
         return stub_worker(args)
 
@@ -696,7 +720,7 @@ def main():
     elif rank == 0:
         out["cpu_baseline"] = None
     if rank == 0:
-        print(json.dumps(out))
+        report(out)
     if multi:
         dist.destroy_process_group()
 

@@ -16,8 +16,9 @@ def test_bench_multi_rank_path_runs_on_rccl_with_one_rank(request):
     rec = getattr(request.config, "_nr_rccl1", None)
     assert rec is not None, "the RCCL run did not happen at session start (NR_SKIP_REHEARSAL=1 or `not gpu` in -m?)"
     assert rec["rc"] == 0, rec["err"] + rec["out"][-2000:]
-    line = [l for l in rec["out"].splitlines() if l.startswith("{")][-1]
-    out = json.loads(line)
+    lines = [l for l in rec["out"].splitlines() if l.strip()]
+    assert len(lines) == 1, "stdout must be the ONE JSON line (RCCL's banner belongs on stderr): " + rec["out"][:600]
+    out = json.loads(lines[0])
     assert out["n_gpus"] == 1 and out["value"] > 0 and out["loss"] == out["loss"]          # finite loss
     ar = out["allreduce"]
     assert ar is not None and ar["backend"] == "nccl" and ar["bytes"] > 40e6                # the flat gradient buffer (46 MB at 300-d)
