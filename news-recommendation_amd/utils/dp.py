@@ -1,9 +1,11 @@
 """Data-parallel gradient averaging for the two-tower model (one process per GPU, RCCL over xGMI).
 
 The reference wraps the model in DistributedDataParallel (main/twotower.py:40-41).  Here the step is: drop the
-gradients -> backward -> multi-tensor copies of the fresh gradients into a flat fp32 buffer laid out
-[dense parameters | token table] -> TWO all-reduces (the 9.4 MB dense part starts when the backward reaches the token
-table's scatter-add and overlaps it; the 36.6 MB table part follows) -> one 1/N scale -> Adam on views of the buffer.
+gradients -> backward of loss with its incoming gradient scaled by 1/N (so every gradient is born pre-divided, as DDP
+pre-divides its buckets) -> one multi-tensor copy of the fresh dense gradients into a flat fp32 buffer laid out
+[dense parameters | token table]; the HIP path scatter-adds the table gradient straight into its slice -> TWO SUM
+all-reduces (the 9.4 MB dense part starts when the backward reaches the token table's scatter-add and overlaps it; the
+36.6 MB table part follows) -> Adam on views of the buffer.
 No per-parameter autograd hooks and no communication thread beside the backward.  The design reason: the token-table
 gradient is the LAST thing the backward produces, so DDP's 25 MB bucket overlap had ~10 MB to hide; two large
 collectives use the xGMI links better than several buckets and keep the step rehearsable on one GPU.
@@ -81,6 +83,19 @@ def all_reduce_async(t):
 LATE_SUFFIXES = ("embedding.weight", "word_embeddings.weight")
 
 
+class _ScaleGrad(torch.autograd.Function):
+    """identity in the forward; the gradient that comes back is multiplied by `c`"""
+
+    @staticmethod
+    def forward(ctx, x, c):
+        ctx.c = c
+        return x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g * ctx.c, None
+
+
 class FlatGradSync(torch.nn.Module):
     """wraps the model like DDP does (`.module`, same forward); call zero_grad() before and sync() after backward.
 
@@ -114,6 +129,8 @@ class FlatGradSync(torch.nn.Module):
             self.n_early = off
         self.flat_early, self.flat_late = self.flat[:self.n_early], self.flat[self.n_early:]
         self._early_done, self._works, self._dirty = False, [], False
+        self._prescaled = False                  # this step's loss went out of forward() with its gradient scaled by 1/N
+        self._claimed = set()                    # late parameters whose gradient was produced in place this step
         if self._reduce:                         # replicas start from rank 0's weights (and buffers), like DDP
             with torch.no_grad():
                 for t in list(module.parameters()) + list(module.buffers()):
@@ -131,19 +148,46 @@ class FlatGradSync(torch.nn.Module):
                     obj.sync_early()
             self._hook = hook
             ops.table_backward_hooks.append(hook)
+            # the token tables' gradients are scatter-added straight into their slices of the flat buffer
+            self._dest_keys = []
+            if self.flat.is_cuda:
+                for i in range(self.n_early_params, len(self.params)):
+                    def dest(i=i):
+                        obj = me()
+                        return obj._claim(i) if obj is not None else None
+                    key = self.params[i].data_ptr()
+                    ops.table_grad_dest[key] = dest
+                    self._dest_keys.append((key, dest))
         except ImportError:
-            self._hook = None
+            self._hook, self._dest_keys = None, []
 
     def __del__(self):
         try:
             from newsrec_hip import ops
             if self._hook in ops.table_backward_hooks:
                 ops.table_backward_hooks.remove(self._hook)
+            for key, dest in self._dest_keys:
+                if ops.table_grad_dest.get(key) is dest:
+                    del ops.table_grad_dest[key]
         except Exception:       # noqa: BLE001 — interpreter shutdown
             pass
 
+    def _claim(self, i):
+        """the flat buffer's slice of late parameter i, for the FIRST gradient of the step that asks (a table looked up twice
+        in one forward gets its second gradient as a fresh tensor, which autograd adds onto the first)"""
+        p = self.params[i]
+        if i in self._claimed or p.grad is not None or p.data_ptr() != self._dest_keys[i - self.n_early_params][0]:
+            return None
+        self._claimed.add(i)
+        return self.views[i].view(p.shape)       # a fresh tensor object on the same memory: autograd keeps it as .grad
+
     def forward(self, *args, **kwargs):
-        return self.module(*args, **kwargs)
+        out = self.module(*args, **kwargs)
+        # the mean over ranks, DDP's way: gradients are born divided by N (exact for 2, 4, 8 ranks) and the all-reduce sums
+        if self._reduce and self.world > 1 and torch.is_tensor(out) and out.requires_grad and not self._prescaled:
+            out = _ScaleGrad.apply(out, 1.0 / self.world)
+            self._prescaled = True
+        return out
 
     def zero_grad(self, set_to_none=False):
         """drop the gradients: the backward then writes fresh tensors (no `grad += new` kernel per parameter, no 46 MB
@@ -156,13 +200,15 @@ class FlatGradSync(torch.nn.Module):
                 if w is not None:
                     w.wait()
         self._early_done, self._works, self._dirty = False, [], False
+        self._prescaled = False
+        self._claimed.clear()
 
     def _pack(self, lo, hi):
         src, dst = [], []
         for p, v in zip(self.params[lo:hi], self.views[lo:hi]):
             if p.grad is None:
                 v.zero_()                            # a parameter the loss did not reach contributes zeros to the average
-            elif p.grad is not v:
+            elif p.grad is not v and p.grad.data_ptr() != v.data_ptr():     # (same memory: produced in place, _claim)
                 src.append(p.grad)
                 dst.append(v)
         if src:
@@ -196,5 +242,5 @@ class FlatGradSync(torch.nn.Module):
             if w is not None:
                 w.wait()
         self._works = []
-        self.flat.div_(self.world)                   # SUM, then one in-place scale (exact for 2, 4, 8 ranks): no reliance on
-                                                     # the backend offering an AVG reduction
+        if not self._prescaled and self.world > 1:   # a loss that did not come out of forward(): SUM, then one in-place scale
+            self.flat.div_(self.world)               # (no reliance on the backend offering an AVG reduction)

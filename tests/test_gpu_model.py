@@ -425,6 +425,54 @@ def test_plan_ahead_changes_nothing():
                 assert torch.equal(gr[n], runs[0][1][n]), n
 
 
+@pytest.mark.parametrize("world", [1, 4])
+def test_flat_grad_sync_packs_in_place_and_prescales(world):
+    """utils/dp.py on the HIP path without a process group (the collectives are skipped, everything else runs): the token
+    table's gradient is scatter-added straight into its slice of the flat buffer (no copy at sync()), every .grad ends up
+    a view of the buffer, and with world = 4 the gradients are born divided by 4 (the loss itself unchanged), which is what
+    the SUM all-reduce needs for DDP's mean (reference main/twotower.py:40-41)."""
+    from newsrec_hip import ops
+    from utils.dp import FlatGradSync
+    meta = dict(V=30522, E=300, D=300, H=12, T=32, L=50, K=4, B=8, Nn=2000)
+    model, mgr = build_model(meta, "tfm", "tfm")
+    g = torch.Generator().manual_seed(77)
+    ids, msk = synth_news_table(g, meta["Nn"], meta["T"], meta["V"])
+    X = {k: v.cuda() for k, v in synth_batch(g, meta["B"], meta["K"] + 1, meta["L"], meta["Nn"], ids, msk).items()}
+    model = model.cuda().train()
+    ops.dropout_stream.reset(0)
+    model.zero_grad(set_to_none=True)
+    loss0 = model(X)
+    loss0.backward()
+    ref = {n: p_.grad.detach().clone() for n, p_ in model.named_parameters()}
+    dp = FlatGradSync(model, world_size=1)       # (no process group here: built as one rank, so no broadcast of the weights,
+    dp.world, dp._reduce = world, world > 1      # then told it is one of `world`; the collectives are replaced below)
+    seen = []
+    dp_sync = dp.sync
+
+    import utils.dp as dpmod
+    real = dpmod.all_reduce_async
+    dpmod.all_reduce_async = lambda t: seen.append(t.numel()) or None
+    try:
+        for _ in range(2):                       # twice: the second step reuses the buffer the first one left gradients in
+            ops.dropout_stream.reset(0)
+            dp.zero_grad()
+            loss = dp(X)
+            loss.backward()
+            table = [i for i, p_ in enumerate(dp.params) if p_ is model.newsEncoder.embedding.weight]
+            assert dp._claimed == set(table), "the table gradient was not produced in the flat buffer"
+            assert model.newsEncoder.embedding.weight.grad.data_ptr() == dp.views[table[0]].data_ptr()
+            dp_sync()
+            assert torch.equal(loss.detach(), loss0.detach())
+            assert all(p_.grad is v for p_, v in zip(dp.params, dp.views))
+            for n, p_ in model.named_parameters():
+                want = ref[n] / world
+                tol = 5e-6 if "embedding" in n else 0.0      # scatter-add by atomics: order-dependent in the last bits
+                assert (p_.grad - want).abs().max().item() <= tol * want.abs().max().item(), n
+    finally:
+        dpmod.all_reduce_async = real
+    assert seen == ([dp.n_early, dp.flat_late.numel()] * 2 if world > 1 else [])
+
+
 def test_nrms_train_step_vs_oracle():
     """BASELINE config 2 shape (T=32, L=50, K=4, 300-d, 12 heads) at B=8: loss, every gradient and one Adam
     step against the oracle (eval-mode dropout so the comparison is deterministic)."""
