@@ -184,7 +184,9 @@ class FlatGradSync(torch.nn.Module):
     def forward(self, *args, **kwargs):
         out = self.module(*args, **kwargs)
         # the mean over ranks, DDP's way: gradients are born divided by N (exact for 2, 4, 8 ranks) and the all-reduce sums
-        if self._reduce and self.world > 1 and torch.is_tensor(out) and out.requires_grad and not self._prescaled:
+        # (every training forward: two losses in one step are both scaled; sync() clears the mark, so a caller that never
+        # calls zero_grad() on the wrapper is scaled on every step too)
+        if self._reduce and self.world > 1 and torch.is_tensor(out) and out.requires_grad:
             out = _ScaleGrad.apply(out, 1.0 / self.world)
             self._prescaled = True
         return out
@@ -244,3 +246,4 @@ class FlatGradSync(torch.nn.Module):
         self._works = []
         if not self._prescaled and self.world > 1:   # a loss that did not come out of forward(): SUM, then one in-place scale
             self.flat.div_(self.world)               # (no reliance on the backend offering an AVG reduction)
+        self._prescaled = False
