@@ -669,7 +669,15 @@ def main():
                 valid = (within[:, None] * Ce + torch.arange(Ce)[None, :]) < ncand[impr_of_row][:, None]
                 Rtot = impr_of_row.numel()
                 cdd_all = (torch.randint(1, NEWS_DEV, (Rtot, Ce), generator=gd) * valid).cuda()
-                his_all = torch.randint(1, NEWS_DEV, (n_impr, L), generator=gd)[impr_of_row].cuda()
+                his_u = torch.randint(1, NEWS_DEV, (n_impr, L), generator=gd)
+                # history lengths as in the train batches (uniform 0..70 truncated to L; empty -> slot 0 kept, news 0)
+                hl = torch.randint(0, 71, (n_impr,), generator=gd).clamp(max=L)
+                live = torch.arange(L)[None, :] < hl[:, None]
+                hm_u = live.long()
+                hm_u[hl == 0, 0] = 1
+                his_all = his_u[impr_of_row].cuda()
+                his_mind = (his_u * live)[impr_of_row].cuda()
+                hm_mind = hm_u[impr_of_row].cuda()
                 lab_all = torch.where(valid, (torch.rand(Rtot, Ce, generator=gd) < 0.1).long(), torch.tensor(-1))
                 lab_all[first, 0], lab_all[first, 1] = 1, 0                               # both classes in every impression
                 lab_all, valid_d, impr_d = lab_all.cuda(), valid.cuda(), impr_of_row.cuda()
@@ -680,33 +688,43 @@ def main():
                 # tensors; rank 0 then computes the per-impression metrics on the device.  Impression ids are made
                 # distinct across ranks (rank * n_impr + i) as the reference's shards are.
                 impr_g = impr_d + rank * n_impr
-                eval_loader = [{"cdd_idx": cdd_all[s:s + 8192], "his_idx": his_all[s:s + 8192], "his_mask": hm[:min(8192, Rtot - s)],
-                                "impr_index": impr_g[s:s + 8192], "cdd_mask": valid_d[s:s + 8192], "label": lab_all[s:s + 8192]}
-                               for s in range(0, Rtot, 8192)]
+                def loader_of(his, mask_of):
+                    return [{"cdd_idx": cdd_all[s:s + 8192], "his_idx": his[s:s + 8192], "his_mask": mask_of(s),
+                             "impr_index": impr_g[s:s + 8192], "cdd_mask": valid_d[s:s + 8192], "label": lab_all[s:s + 8192]}
+                            for s in range(0, Rtot, 8192)]
+                loader_full = loader_of(his_all, lambda s: hm[:min(8192, Rtot - s)])          # every one of the 50 slots clicked
+                loader_mind = loader_of(his_mind, lambda s: hm_mind[s:s + 8192])              # MIND-like history lengths
                 mgr.impr_size = Ce
 
-                def full_eval():
-                    res = model._predict(mgr, eval_loader, with_labels=True, to_host=False)
+                def full_eval(loader):
+                    res = model._predict(mgr, loader, with_labels=True, to_host=False)
                     if res is None:
                         return None
                     impr, masks, preds, labels = res
                     return device_compute_metrics(impr, masks, preds, labels, ["auc", "mean_mrr", "ndcg@5;10"])
-                full_eval()
-                fence()
-                t0 = time.perf_counter()
-                met = full_eval()
-                fence()
-                t_full = time.perf_counter() - t0
+
+                def timed_eval(loader):
+                    full_eval(loader)
+                    fence()
+                    t0 = time.perf_counter()
+                    m = full_eval(loader)
+                    fence()
+                    return time.perf_counter() - t0, m
+                t_full, met = timed_eval(loader_full)
+                t_mind, _ = timed_eval(loader_mind)
             if multi:
-                t_enc, t_inf, t_full = reduce_max([t_enc, t_inf, t_full])
+                t_enc, t_inf, t_full, t_mind = reduce_max([t_enc, t_inf, t_full, t_mind])
             out["eval"] = {"news_cache_rows": NEWS_DEV, "cache_build_news_per_s": round(NEWS_DEV / t_enc, 1),
                            "infer_rows_per_s_batch200": round(world * n_it * Re / t_inf, 1),
                            "eval_impressions_per_s": round(world * n_impr / t_full, 1),
                            "eval_rows_per_s": round(world * Rtot / t_full, 1),
+                           "eval_impressions_per_s_mind_like_histories": round(world * n_impr / t_mind, 1),
                            "note": "cache build = TwoTowerBaseModel.encode_news over the 72 024-news corpus (sharded over the ranks + "
                                    "all-gather, tfm encoder); batch200 = the reference's -bse default; eval_impressions_per_s = 40 000 "
-                                   "impressions per GPU (2..80 candidates, L=50, tfm user encoder) through _predict (8192-row batches, "
-                                   "typed gather to rank 0) + device AUC/MRR/nDCG@5/10 on rank 0, end to end",
+                                   "impressions per GPU (2..80 candidates, L=50, tfm user encoder, ALL 50 history slots clicked) through "
+                                   "_predict (8192-row batches, typed gather to rank 0) + device AUC/MRR/nDCG@5/10 on rank 0, end to end; "
+                                   "..._mind_like_histories = the same with the train batches' history lengths (uniform 0..70 truncated "
+                                   "to 50, SURVEY 8d): the user tower then runs over the clicked slots only (TfmUserEncoder.from_cache)",
                            "metrics_of_random_scores": met}
 
         except Exception as e:                 # noqa: BLE001 — reported in the JSON line

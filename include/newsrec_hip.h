@@ -238,7 +238,9 @@ int nr_tfm_layer_bwd_f32(const float* dy, const float* x, const int64_t* mask, i
  *   their news vectors reach nothing that is kept and receive exactly zero gradient; pooling returns a zero vector
  *   for them.  nr_pack_ids: ids_packed [R], row_map [R] (packed row -> n*T + j).
  * The *_packed_* entry points take x / y / saved activations with R rows (allocate nr_tfm_saved for R rows, stats
- * [4,R]; row_max/row_sum stay [N,H,S]) and need S <= 32, head dim <= 64; workspace: nr_tfm_layer_bwd_ws_bytes(R, 1, D). */
+ * [4,R]; row_max/row_sum stay [N,H,S]) and need S <= 32, head dim <= 64; workspace: nr_tfm_layer_bwd_ws_bytes(R, 1, D).
+ * nr_tfm_layer_packed_fwd_f32 alone also takes 32 < S <= 64 (round 3: the user tower of cached evaluation over the clicked
+ * history slots only, BaseModel.py:208-218 / encoder.py:314-327; the packed backward refuses it with NR_ERR_UNSUPPORTED). */
 int nr_pack_plan(const int64_t* mask, const int64_t* title_keep, int64_t N, int64_t T, int32_t* offs, int32_t* info, void* stream);
 int nr_pack_ids(const int64_t* ids, const int32_t* offs, int64_t N, int64_t T, int64_t* ids_packed, int32_t* row_map, void* stream);
 int nr_tfm_layer_packed_fwd_f32(const float* x, const int64_t* mask, const int32_t* offs, const int32_t* row_map, int64_t N, int64_t S, int64_t R, int64_t D, int64_t H, const nr_tfm_weights* w, float p_drop, uint64_t seed, uint32_t site_base, int mask_mode, nr_tfm_saved* saved, float* y, void* stream);

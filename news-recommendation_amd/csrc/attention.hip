@@ -345,11 +345,11 @@ int mhsa_fwd(const float* qkv, const int64_t* mask, float* ctx, float* row_max, 
         ProfScope prof(FAM_ATTN, s, 4.0 * N * H * S * S * dh);
         return mhsa_fwd_mfma(qkv, mask, ctx, row_max, row_sum, N, S, H, dh, dc, s);
     }
-    if (mhsa_mfma2_supported(S, dh) && !dc.offs) {
+    if (mhsa_mfma2_supported(S, dh)) {                        // (packed rows too: forward only, see mhsa_bwd)
         ProfScope prof(FAM_ATTN, s, 4.0 * N * H * S * S * dh);
         return mhsa_fwd_mfma2(qkv, mask, ctx, row_max, row_sum, N, S, H, dh, dc, s);
     }
-    NR_UNSUPPORTED(dc.offs != nullptr, "mhsa: packed sequences need S <= 32 and head dim <= 64 (got S=%d, dh=%d)", S, dh);
+    NR_UNSUPPORTED(dc.offs != nullptr, "mhsa: packed sequences need S <= 64 and head dim <= 64 (got S=%d, dh=%d)", S, dh);
     NR_UNSUPPORTED(S > 128 || S < 1, "mhsa: sequence length %d not in [1,128]", S);
     const int dhp = pick_dhp(dh);
     NR_UNSUPPORTED(dhp == 0, "mhsa: head dim %d > 128", dh);
@@ -380,7 +380,7 @@ int mhsa_bwd(const float* qkv, const int64_t* mask, const float* ctx, const floa
         ProfScope prof(FAM_ATTN, s, 10.0 * N * H * S * S * dh);
         return mhsa_bwd_mfma2(qkv, mask, dctx, row_max, row_sum, dqkv, N, S, H, dh, dc, s);
     }
-    NR_UNSUPPORTED(dc.offs != nullptr, "mhsa bwd: packed sequences need S <= 32 and head dim <= 64 (got S=%d, dh=%d)", S, dh);
+    NR_UNSUPPORTED(dc.offs != nullptr, "mhsa bwd: packed sequences need S <= 32 and head dim <= 64 (got S=%d, dh=%d; 32 < S <= 64 is packed in the forward only)", S, dh);
     NR_UNSUPPORTED(S > 128 || S < 1, "mhsa bwd: sequence length %d not in [1,128]", S);
     const int dhp = pick_dhp(dh);
     NR_UNSUPPORTED(dhp == 0 || dhp > 64, "mhsa bwd: head dim %d > 64", dh);

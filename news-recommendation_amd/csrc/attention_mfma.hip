@@ -551,20 +551,24 @@ __global__ __launch_bounds__(128 * NHG) void mhsa_fwd_mfma2_kernel(const float* 
     const bool active = hw < nh;
     const int A = H * dh;
     const int64_t ld = 3 * (int64_t)A;
-    const int64_t row0 = (int64_t)n * S;
+    // packed layout (forward only: the cached-evaluation user tower): this sequence owns rows offs[n] .. offs[n+1]
+    // (Sn <= S of them); S stays the ORIGINAL length for every index that names a position
+    const int64_t row0 = dc.offs ? (int64_t)dc.offs[n] : (int64_t)n * S;
+    const int Sn = dc.offs ? dc.offs[n + 1] - dc.offs[n] : S;
+    if (Sn == 0) return;                                        // block-uniform
     const float* base = qkv + row0 * ld + hd0 * dh;
     float* Mk = Vt + NHG * TS;         // [64] additive key-mask term of this sequence
-    if (tid < 64) Mk[tid] = tid < S ? (mask[(int64_t)n * S + tid] ? 0.f : dc.mask_fill) : -INFINITY;
+    if (tid < 64) Mk[tid] = tid < Sn ? (mask[(int64_t)n * S + tid] ? 0.f : dc.mask_fill) : -INFINITY;
     {
         float* const tl[3] = {Qt, Kt, Vt};
         const float* const gp[3] = {base, base + A, base + 2 * A};
         const int64_t lds3[3] = {ld, ld, ld};
-        heads_in_n<DHP, 64, 3>(tl, gp, lds3, S, dh, nh, tid, vec, NTHR);
+        heads_in_n<DHP, 64, 3>(tl, gp, lds3, Sn, dh, nh, tid, vec, NTHR);
     }
     float* Qs = Qt + hw * TS; float* Ks = Kt + hw * TS; float* Vs = Vt + hw * TS;
     if (active) {
-        if (t == 0) { tile_zero_pad<64>(Qs, S, dh, lane); tile_zero_pad<64>(Ks, S, dh, lane); }
-        else tile_zero_pad<64>(Vs, S, dh, lane);
+        if (t == 0) { tile_zero_pad<64>(Qs, Sn, dh, lane); tile_zero_pad<64>(Ks, Sn, dh, lane); }
+        else tile_zero_pad<64>(Vs, Sn, dh, lane);
     }
     AT_STAMP(2);
     __syncthreads();
@@ -599,7 +603,7 @@ __global__ __launch_bounds__(128 * NHG) void mhsa_fwd_mfma2_kernel(const float* 
         sum += __shfl_xor(sum, 32, 64);
         if (sum == 0.f) sum = 1.f;
         const int64_t qrow = ((int64_t)n * H + hd) * S + q;
-        if (row_max && h == 0 && q < S) { row_max[qrow] = m; row_sum[qrow] = sum; }
+        if (row_max && h == 0 && q < Sn) { row_max[qrow] = m; row_sum[qrow] = sum; }
         const float scale = dc.p > 0.f ? 1.0f / (1.0f - dc.p) : 1.f;
         uint64_t keep = ~0ull;
         if (dc.p > 0.f) keep = keep_word64(dc, drop_threshold(dc.p), qrow, S, h);
@@ -629,7 +633,7 @@ __global__ __launch_bounds__(128 * NHG) void mhsa_fwd_mfma2_kernel(const float* 
     AT_STAMP(7);
     __syncthreads();
     AT_STAMP(8);
-    heads_out<DHP, 64>(ctx + row0 * A + hd0 * dh, A, Qt, S, dh, nh, tid, vec, NTHR);
+    heads_out<DHP, 64>(ctx + row0 * A + hd0 * dh, A, Qt, Sn, dh, nh, tid, vec, NTHR);
     AT_STAMP(9); AT_STAMP_RT(10);
 }
 

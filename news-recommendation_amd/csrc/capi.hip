@@ -717,7 +717,9 @@ int nr_tfm_layer_fwd_f32(const float* x, const int64_t* mask, int64_t N, int64_t
 int nr_tfm_layer_packed_fwd_f32(const float* x, const int64_t* mask, const int32_t* offs, const int32_t* row_map, int64_t N, int64_t Sq, int64_t R, int64_t D, int64_t H, const nr_tfm_weights* w, float p_drop, uint64_t seed, uint32_t site_base, int mask_mode, nr_tfm_saved* sv, float* y, void* stream) {
     NR_CHECK_ARG(offs && row_map, "tfm_layer_packed_fwd: null offsets / row map");
     NR_CHECK_ARG(R <= N * Sq, "tfm_layer_packed_fwd: %lld packed rows exceed N*S = %lld", (long long)R, (long long)(N * Sq));
-    NR_UNSUPPORTED(!mhsa_mfma_supported((int)Sq, (int)(H > 0 ? D / H : 0)), "tfm_layer_packed_fwd: packed sequences need S <= 32 and head dim <= 64");
+    // 32 < S <= 64 (a user's history): forward only — nr_tfm_layer_packed_bwd_f32 refuses it, so sv needs no backward buffers
+    NR_UNSUPPORTED(!mhsa_mfma_supported((int)Sq, (int)(H > 0 ? D / H : 0)) && !mhsa_mfma2_supported((int)Sq, (int)(H > 0 ? D / H : 0)),
+                   "tfm_layer_packed_fwd: packed sequences need S <= 64 and head dim <= 64");
     return tfm_layer_fwd(x, mask, N, Sq, R, D, H, w, p_drop, seed, site_base, mask_mode, sv, y, offs, row_map, S(stream));
 }
 

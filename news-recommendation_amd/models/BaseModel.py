@@ -125,6 +125,9 @@ def _gather_to_rank0(t, world_size, rank):
 
 class TwoTowerBaseModel(BaseModel):
     """two-tower models: every news vector can be cached once and reused when scoring."""
+    # cached inference runs a Tfm user tower over the clicked history slots only (TfmUserEncoder.from_cache);
+    # NR_PACKED_HISTORY=0 keeps the padded [B, L] layout (A/B measurements)
+    packed_history = os.environ.get("NR_PACKED_HISTORY", "1") != "0"
 
     def __init__(self, manager, name=None):
         super().__init__(manager, name)
@@ -272,8 +275,13 @@ class TwoTowerBaseModel(BaseModel):
         elif kind == "AttnUserEncoder":
             user = ops.pool_from_table(self.news_embeddings, his_idx, self.userEncoder.user_query)
         else:
-            his = ops.gather_rows(self.news_embeddings, his_idx)
-            user = self._encode_user(his_news_embedding=his, his_mask=his_mask.to(self.device))
+            his_mask = his_mask.to(self.device)
+            user = None
+            if hasattr(self.userEncoder, "from_cache") and getattr(self, "packed_history", True):
+                user = self.userEncoder.from_cache(self.news_embeddings, his_idx, his_mask)     # clicked slots only
+            if user is None:
+                his = ops.gather_rows(self.news_embeddings, his_idx)
+                user = self._encode_user(his_news_embedding=his, his_mask=his_mask)
         return user
 
     def _check_indices(self, where):

@@ -520,11 +520,15 @@ def _carve(device, sizes):
 
 class _TFMLayer(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, mask, H, p, seed, site, mask_mode, plan, *params):
+    def forward(ctx, x, mask, H, p, seed, site, mask_mode, plan, grad_mode, *params):
         N, S = mask.shape
         D = x.shape[-1]
         R = N * S if plan is None else plan.rows      # packed: x is [R, D]
-        train = any(ctx.needs_input_grad)       # False under no_grad / eval-only calls
+        # grad_mode = torch.is_grad_enabled() at the call (inside a Function's forward it always reads False, and
+        # needs_input_grad ignores no_grad: parameters "need" gradients in evaluation too): no backward buffers under no_grad
+        train = grad_mode and any(ctx.needs_input_grad)
+        if train and plan is not None and S > 32:
+            raise NewsrecError(f"tfm_layer: packed sequences of {S} > 32 positions are forward-only (no packed backward)")
         sizes = [3 * D * D, 3 * D, R * 3 * D, R * D, R * D, R * D, R * 4 * D if train else 0, R * 4 * D, R * D,
                  4 * R if train else 0, N * H * S if train else 0, N * H * S if train else 0]
         buf, ptrs = _carve(x.device, sizes)           # wqkv bqkv qkv ctx s1 y1 z a s2 stats rmax rsum
@@ -573,7 +577,7 @@ class _TFMLayer(torch.autograd.Function):
             check(L.nr_tfm_layer_packed_bwd_f32(_p(g), _p(x), _p(mask), _p(plan.offs), _p(plan.row_map), N, S, R, D, H, C.byref(W), p,
                                                 seed, site, mask_mode, C.byref(SV), C.byref(G), _p(dx), _p(ws), ws.numel() * 4,
                                                 _stream()), "nr_tfm_layer_packed_bwd_f32")
-        return (dx, None, None, None, None, None, None, None) + tuple(grads[n] for n in _TFM_ORDER)
+        return (dx, None, None, None, None, None, None, None, None) + tuple(grads[n] for n in _TFM_ORDER)
 
 
 class _TFMLayerBf16(torch.autograd.Function):
@@ -581,16 +585,17 @@ class _TFMLayerBf16(torch.autograd.Function):
     residual stream / LayerNorm / softmax / parameter gradients f32"""
 
     @staticmethod
-    def forward(ctx, x, mask, H, p, seed, site, mask_mode, plan, *params):
+    def forward(ctx, x, mask, H, p, seed, site, mask_mode, plan, grad_mode, *params):
         N, S = mask.shape
         D = x.shape[-1]
         R = N * S if plan is None else plan.rows
+        train = grad_mode and any(ctx.needs_input_grad)          # (see _TFMLayer.forward)
         dev = x.device
         h = lambda *shape: torch.empty(*shape, dtype=torch.bfloat16, device=dev)
         f = lambda *shape: torch.empty(*shape, dtype=torch.float32, device=dev)
         bufs = dict(x_h=h(R, D), qkv_h=h(R, 3 * D), ctx_h=h(R, D), y1_h=h(R, D), z_h=h(R, 4 * D), a_h=h(R, 4 * D), s1=f(R, D), y1=f(R, D),
                     s2=f(R, D), stats=f(4, R), row_max=f(N, H, S), row_sum=f(N, H, S), w_h=h(12 * D * D))
-        if any(ctx.needs_input_grad):
+        if train:
             bufs["wT_h"] = h(12 * D * D)                    # transposed bf16 weights: written with w_h, read by the backward's dX products
         y = torch.empty_like(x)
         W = TfmWeights(*[_p(t) for t in params])
@@ -598,7 +603,7 @@ class _TFMLayerBf16(torch.autograd.Function):
         offs, row_map = (None, None) if plan is None else (plan.offs, plan.row_map)
         check(lib().nr_tfm_layer_fwd_bf16(_p(x), _p(mask), _p(offs), _p(row_map), N, S, R, D, H, C.byref(W), p, seed, site, mask_mode,
                                           C.byref(SV), _p(y), _stream()), "nr_tfm_layer_fwd_bf16")
-        if any(ctx.needs_input_grad):
+        if train:
             bufs.pop("y1"), bufs.pop("w_h")                 # forward-only scratch
             ctx.names = list(bufs)
             ctx.save_for_backward(mask, *bufs.values(), *params)
@@ -627,7 +632,7 @@ class _TFMLayerBf16(torch.autograd.Function):
         ws = _ws(L.nr_tfm_layer_bwd_bf16_ws_bytes(R, D), g.device)
         check(L.nr_tfm_layer_bwd_bf16(_p(g), _p(mask), _p(offs), _p(row_map), N, S, R, D, H, C.byref(W), p, seed, site, mask_mode, C.byref(SV),
                                       C.byref(G), _p(dx), _p(ws), ws.numel() * 4, _stream()), "nr_tfm_layer_bwd_bf16")
-        return (dx, None, None, None, None, None, None, None) + tuple(grads[n] for n in _TFM_ORDER)
+        return (dx, None, None, None, None, None, None, None, None) + tuple(grads[n] for n in _TFM_ORDER)
 
 
 def _contiguous3(a, b, c):
@@ -663,8 +668,10 @@ def tfm_layer(x, mask, head_num, params, p_drop=0.0, seed=0, site=0, hf_mask=Fal
     if (get_gemm_compute() == "bf16" and tfm_layer_bf16_supported(mask.shape[1], D, int(head_num)) and rows >= 128
             and _contiguous3(plist[0], plist[2], plist[4]) and _contiguous3(plist[1], plist[3], plist[5])):
         # the bf16 build proper: activations / attention tensors bf16 in HBM (BERT-sized layers, parity bar 1e-2)
-        return _TFMLayerBf16.apply(x, mask, int(head_num), float(p_drop), int(seed), int(site), 1 if hf_mask else 0, plan, *plist)
-    return _TFMLayer.apply(x, mask, int(head_num), float(p_drop), int(seed), int(site), 1 if hf_mask else 0, plan, *plist)
+        return _TFMLayerBf16.apply(x, mask, int(head_num), float(p_drop), int(seed), int(site), 1 if hf_mask else 0, plan,
+                                   torch.is_grad_enabled(), *plist)
+    return _TFMLayer.apply(x, mask, int(head_num), float(p_drop), int(seed), int(site), 1 if hf_mask else 0, plan,
+                           torch.is_grad_enabled(), *plist)
 
 
 # ----------------------------------------------------------------------------- GRU user encoder
@@ -682,10 +689,10 @@ class _GRUFinal(torch.autograd.Function):
     """final state of nn.GRU over a packed batch (RnnUserEncoder.forward, encoder.py:216-233)."""
 
     @staticmethod
-    def forward(ctx, x, mask, w_ih, w_hh, b_ih, b_hh):
+    def forward(ctx, x, mask, w_ih, w_hh, b_ih, b_hh, grad_mode):
         B, L, Din = x.shape
         H = w_hh.shape[1]
-        train = any(ctx.needs_input_grad)
+        train = grad_mode and any(ctx.needs_input_grad)          # (see _TFMLayer.forward)
         dev = x.device
         gi = torch.empty(B * L, 3 * H, dtype=torch.float32, device=dev)
         gh = torch.empty(B, 3 * H, dtype=torch.float32, device=dev)
@@ -718,7 +725,7 @@ class _GRUFinal(torch.autograd.Function):
                                 _p(dw_hh), _p(db_ih), _p(db_hh), _p(ws), ws.numel() * 4, _stream()), "nr_gru_bwd_f32")
         global _last_gru_ws
         _last_gru_ws = ws
-        return dx, None, dw_ih, dw_hh, db_ih, db_hh
+        return dx, None, dw_ih, dw_hh, db_ih, db_hh, None
 
 
 def gru_final_state(x, mask, w_ih, w_hh, b_ih, b_hh):
@@ -727,7 +734,7 @@ def gru_final_state(x, mask, w_ih, w_hh, b_ih, b_hh):
     if x.dim() != 3 or mask.shape != x.shape[:2]:
         raise NewsrecError(f"gru_final_state: x {tuple(x.shape)} / mask {tuple(mask.shape)} shape mismatch")
     return _GRUFinal.apply(x, mask, _f32(w_ih, "rnn.weight_ih_l0"), _f32(w_hh, "rnn.weight_hh_l0"), _f32(b_ih, "rnn.bias_ih_l0"),
-                           _f32(b_hh, "rnn.bias_hh_l0"))
+                           _f32(b_hh, "rnn.bias_hh_l0"), torch.is_grad_enabled())
 
 
 # ----------------------------------------------------------------------------- BERT embedding stage

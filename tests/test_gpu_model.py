@@ -473,6 +473,53 @@ def test_flat_grad_sync_packs_in_place_and_prescales(world):
     assert seen == ([dp.n_early, dp.flat_late.numel()] * 2 if world > 1 else [])
 
 
+@pytest.mark.parametrize("gemm", ["fp32-mfma", "fp32"])
+def test_cached_inference_over_clicked_slots_only(gemm):
+    """TfmUserEncoder.from_cache (BaseModel.infer's user tower over the his_mask == 1 slots only: packed rows through the
+    layer, the 50-slot attention kernel and the pooling) against the padded forward — reference BaseModel.py:208-218,
+    encoder.py:314-327: masked slots carry weight exactly 0 there.  On ONE GEMM kernel ("fp32-mfma") the user vectors are
+    the very same bits; in the default mode the row count picks the kernel per product (7 600 packed rows against 15 000), so
+    they are held to 2e-6 like the packed title layer.  Histories of 1, 2, 33, 49, 50 and random lengths; a mask that is
+    not prefix-shaped takes the padded path."""
+    from newsrec_hip import ops
+    ops.set_gemm_compute(gemm)
+    try:
+        _cached_inference_case(ops, exact=(gemm == "fp32-mfma"))
+    finally:
+        ops.set_gemm_compute("fp32")
+
+
+def _cached_inference_case(ops, exact):
+    meta = dict(V=30522, E=300, D=300, H=12, T=32, L=50, K=4, B=8, Nn=3000)
+    model, mgr = build_model(meta, "tfm", "tfm")
+    model = model.cuda().eval()
+    model.userEncoder.pack_min_slots = 0                     # (the product packs from 65 536 history slots on)
+    g = torch.Generator().manual_seed(91)
+    cache = torch.randn(meta["Nn"], meta["D"], generator=g).cuda()
+    B, L = 300, meta["L"]
+    lens = torch.randint(1, L + 1, (B,), generator=g)
+    lens[:5] = torch.tensor([1, 2, 33, 49, 50])
+    his_mask = (torch.arange(L)[None, :] < lens[:, None]).long().cuda()
+    his_idx = torch.randint(1, meta["Nn"], (B, L), generator=g).cuda() * his_mask          # padded slots point at news 0
+    with torch.no_grad():
+        packed = model.userEncoder.from_cache(cache, his_idx, his_mask)
+        padded = model.userEncoder(ops.gather_rows(cache, his_idx), his_mask)
+        assert packed is not None and packed.shape == padded.shape == (B, 1, meta["D"])
+        same = (lambda a_, b_: torch.equal(a_, b_)) if exact else (lambda a_, b_: relerr(a_, b_) < 2e-6)
+        assert same(packed, padded)
+        holes = his_mask.clone()
+        holes[7, 0] = 0                                                                     # not a prefix: no packing
+        assert lens[7] > 1 and model.userEncoder.from_cache(cache, his_idx, holes) is None
+        # infer() end to end: the same logits with and without the packed history
+        model.news_embeddings = cache
+        x = {"cdd_idx": torch.randint(1, meta["Nn"], (B, 20), generator=g), "his_idx": his_idx.cpu(), "his_mask": his_mask.cpu()}
+        a = model.infer(x)
+        model.packed_history = False
+        b = model.infer(x)
+        assert same(a, b)
+    assert model.userEncoder.from_cache(cache, his_idx, his_mask) is None                   # gradients wanted: padded path
+
+
 def test_nrms_train_step_vs_oracle():
     """BASELINE config 2 shape (T=32, L=50, K=4, 300-d, 12 heads) at B=8: loss, every gradient and one Adam
     step against the oracle (eval-mode dropout so the comparison is deterministic)."""
