@@ -668,7 +668,12 @@ def main():
                 within = torch.arange(int(nrow.sum())) - first[impr_of_row]
                 valid = (within[:, None] * Ce + torch.arange(Ce)[None, :]) < ncand[impr_of_row][:, None]
                 Rtot = impr_of_row.numel()
-                cdd_all = (torch.randint(1, NEWS_DEV, (Rtot, Ce), generator=gd) * valid).cuda()
+                # an impression never lists a news twice (duplicates score exact ties, which the metrics re-rank on the host
+                # with numpy's tie order: 4 % of random 40-candidate lists would take that path, none of MIND's): candidate j
+                # of impression i is news 1 + (s_i + 7919 j) mod (Nn - 1), distinct for j < 80
+                s_i = torch.randint(0, NEWS_DEV - 1, (n_impr,), generator=gd)[impr_of_row]
+                jj = within[:, None] * Ce + torch.arange(Ce)[None, :]
+                cdd_all = ((1 + (s_i[:, None] + 7919 * jj) % (NEWS_DEV - 1)) * valid).cuda()
                 his_u = torch.randint(1, NEWS_DEV, (n_impr, L), generator=gd)
                 # history lengths as in the train batches (uniform 0..70 truncated to L; empty -> slot 0 kept, news 0)
                 hl = torch.randint(0, 71, (n_impr,), generator=gd).clamp(max=L)
@@ -721,7 +726,7 @@ def main():
                            "eval_impressions_per_s_mind_like_histories": round(world * n_impr / t_mind, 1),
                            "note": "cache build = TwoTowerBaseModel.encode_news over the 72 024-news corpus (sharded over the ranks + "
                                    "all-gather, tfm encoder); batch200 = the reference's -bse default; eval_impressions_per_s = 40 000 "
-                                   "impressions per GPU (2..80 candidates, L=50, tfm user encoder, ALL 50 history slots clicked) through "
+                                   "impressions per GPU (2..80 DISTINCT candidates each, L=50, tfm user encoder, ALL 50 history slots clicked) through "
                                    "_predict (8192-row batches, typed gather to rank 0) + device AUC/MRR/nDCG@5/10 on rank 0, end to end; "
                                    "..._mind_like_histories = the same with the train batches' history lengths (uniform 0..70 truncated "
                                    "to 50, SURVEY 8d): the user tower then runs over the clicked slots only (TfmUserEncoder.from_cache)",
