@@ -175,8 +175,8 @@ def test_bench_launcher_starts_its_own_ranks():
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "2", "--batch-size", "4"],
                        env=env, capture_output=True, text=True, timeout=240)
     assert r.returncode == 0, r.stderr[-2000:]
-    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
-    assert len(lines) == 1, r.stdout
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, r.stdout                 # stdout is the JSON line alone (gloo's connection lines are on stderr)
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["steps"] == 6 and out["warmup"] == 2 and out["stub"] is True
     assert out["replicas_identical"] and out["value"] > 0 and out["ms_per_step"] > 0
