@@ -1,7 +1,9 @@
 """what bounds gemm_x3_kernel on the NRMS shapes: the same launches on diagnostic builds of gemm.hip (-DNR_X3_EXP=1: no
 operand split arithmetic, 2: one of the six MFMAs, 3: no epilogue, 5: one MFMA but every fragment read, 6: half of the
 fragment reads, 7: no split / LDS stores after the first k-tile, 8: no global loads after the second k-tile), each build in its own process (the variant library is
-swapped in by pointing newsrec_hip._lib.LIB_PATH at it before the first call).  usage: python tools/gemm_exp.py LIB"""
+swapped in by pointing newsrec_hip._lib.LIB_PATH at it before the first call; build it with
+`make -C news-recommendation_amd/csrc variant NAME=e1 EXTRA=-DNR_X3_EXP=1`, which keeps gemm.hip's own flags).
+usage: python tools/gemm_exp.py libnewsrec_hip_e1.so"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "news-recommendation_amd"))
