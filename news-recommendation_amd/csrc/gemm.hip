@@ -914,6 +914,9 @@ struct LoaderKCX {
 #ifndef NR_X3_WGS
 #define NR_X3_WGS 2
 #endif
+#ifndef NR_X3_IGLP
+#define NR_X3_IGLP 0                                       // -1: no iglp_opt in gemm_x3_kernel's k-loop (A/B builds)
+#endif
 #if NR_X3_EXP == 4
 // diagnostic build only (never shipped: the default build has none of this): per-workgroup cycle stamps of the x3 kernel
 __device__ unsigned long long x3_stamps[8192 * 32];
@@ -1190,6 +1193,11 @@ __global__ __launch_bounds__(256, NR_X3_WGS) void gemm_x3_kernel(const GemmParam
 #endif
         fmma(f0);
         fmma(f1);
+#if NR_X3_IGLP >= 0
+        // the compiler's own DS / MFMA interleaving pattern for this block; together with -mllvm -enable-post-misched=0
+        // (Makefile) 2.3 % on the twelve NRMS products, three alternating rounds (1 082 -> 1 057 us summed; either alone 0.7 / 1.2 %)
+        __builtin_amdgcn_iglp_opt(NR_X3_IGLP);
+#endif
 #endif
         if (kt - kt_begin < 6) X3_STAMP(3 + 4 * (kt - kt_begin));
         __syncthreads();                                  // everyone is done reading the single stage
